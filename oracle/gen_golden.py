@@ -1,0 +1,179 @@
+"""Generate golden fixtures by running the REFERENCE's own importable code on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
+
+    python oracle/gen_golden.py
+
+Imports ``model/abc_util.py`` (compute_contrastive_loss / compute_gathered_loss) and
+``visualization/neg_mine.py`` (batch) from the reference and stores inputs + outputs as
+small .npz files under tests/golden/.  Only data is stored, never reference source.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REF = os.environ.get("ABC_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _ref():
+    sys.path.insert(0, REF)
+    from model import abc_util  # noqa
+    from visualization import neg_mine  # noqa
+    return abc_util, neg_mine
+
+
+class _Temp(torch.nn.Module):
+    # stand-in with the contract of model/modeling_abc.py:36-43 (that file needs `timm`)
+    def __init__(self, t):
+        super().__init__()
+        self.temp = torch.nn.Parameter(torch.tensor(t, dtype=torch.float32))
+
+    def forward(self, x):
+        return x / (self.temp.float())
+
+
+def bf16_bits(x: torch.Tensor) -> np.ndarray:
+    return x.to(torch.bfloat16).view(torch.int16).numpy().copy()
+
+
+def _unit(n, d, g):
+    return torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=-1)
+
+
+def gen_loss(abc_util):
+    cases = {}
+    n = 0
+    for B in (4, 32):
+        for mult in (1, 8):
+            for eps in (0.0, 0.1):
+                for t in (0.07, 0.02):
+                    g = torch.Generator().manual_seed(100 + n)
+                    D = 64
+                    q = _unit(B, D, g).requires_grad_(True)
+                    p = _unit(B * mult, D, g)
+                    # make positives correlated so accuracy is non-trivial
+                    p[:B] = torch.nn.functional.normalize(q.detach() + 0.8 * p[:B], dim=-1)
+                    p.requires_grad_(True)
+                    temp = _Temp(t)
+                    loss, acc = abc_util.compute_contrastive_loss(q, p, temp, label_smoothing=eps)
+                    loss.backward()
+                    pre = f"c{n}_"
+                    cases.update({pre + "q": q.detach().numpy(), pre + "p": p.detach().numpy(),
+                                  pre + "temp": np.float32(t), pre + "eps": np.float32(eps),
+                                  pre + "loss": loss.detach().numpy(), pre + "acc": acc.numpy(),
+                                  pre + "dq": q.grad.numpy(), pre + "dp": p.grad.numpy(),
+                                  pre + "dtemp": temp.temp.grad.numpy()})
+                    n += 1
+    cases["n_cases"] = np.int64(n)
+    np.savez_compressed(os.path.join(OUT, "loss_small.npz"), **cases)
+
+    # BASELINE config 4 on one rank: B=128, C=1024, D=4096, eps=0.1, temp=0.07; seed-defined inputs
+    g = torch.Generator().manual_seed(4242)
+    q = _unit(128, 4096, g)
+    p = _unit(1024, 4096, g)
+    p[:128] = torch.nn.functional.normalize(q + 0.9 * p[:128], dim=-1)
+    q.requires_grad_(True)
+    p.requires_grad_(True)
+    temp = _Temp(0.07)
+    loss, acc = abc_util.compute_contrastive_loss(q, p, temp, label_smoothing=0.1)
+    loss.backward()
+    np.savez_compressed(os.path.join(OUT, "loss_cfg4.npz"), seed=np.int64(4242), loss=loss.detach().numpy(),
+                        acc=acc.numpy(), dtemp=temp.temp.grad.numpy(),
+                        dq_rows=q.grad[:4].numpy(), dp_rows=p.grad[:4].numpy(),
+                        dq_colsum=q.grad.sum(0).numpy(), dp_colsum=p.grad.sum(0).numpy(),
+                        dq_abs=q.grad.abs().sum().numpy(), dp_abs=p.grad.abs().sum().numpy())
+
+
+def _gather_worker(rank, world, port, B, mult, D, eps, t, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    abc_util, _ = _ref()
+    g = torch.Generator().manual_seed(7000 + rank)
+    q = _unit(B, D, g)
+    c = _unit(B * mult, D, g)
+    c[:B] = torch.nn.functional.normalize(q + 0.8 * c[:B], dim=-1)
+    q.requires_grad_(True)
+    c.requires_grad_(True)
+    temp = _Temp(t)
+    loss, acc, num = abc_util.compute_gathered_loss(q, c, temp, label_smoothing=eps)
+    loss.backward()
+    ret[rank] = dict(q=q.detach().numpy(), c=c.detach().numpy(), loss=loss.detach().numpy(), acc=acc.numpy(),
+                     num=num.numpy(), dq=q.grad.numpy(), dc=c.grad.numpy(), dtemp=temp.temp.grad.numpy())
+    dist.destroy_process_group()
+
+
+def gen_gathered():
+    out = {}
+    port = 29611
+    for world in (2, 4):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        B, mult, D, eps, t = 4, 2, 64, 0.1, 0.07
+        mp.spawn(_gather_worker, args=(world, port, B, mult, D, eps, t, ret), nprocs=world, join=True)
+        port += 1
+        for r in range(world):
+            for k, v in ret[r].items():
+                out[f"w{world}_r{r}_{k}"] = v
+        out[f"w{world}_cfg"] = np.array([B, mult, D], dtype=np.int64)
+        out[f"w{world}_eps"] = np.float32(eps)
+        out[f"w{world}_temp"] = np.float32(t)
+    np.savez_compressed(os.path.join(OUT, "gathered_gloo.npz"), **out)
+
+
+def gen_neg_mine(neg_mine):
+    from oracle.search_oracle import make_clustered
+    out = {}
+    # small case with stored bf16-exact inputs
+    q, c = make_clustered(512, 512, 128, seed=31, n_centres=16)
+    q, c = q.to(torch.bfloat16).float(), c.to(torch.bfloat16).float()
+    out["s_q_bf16"] = bf16_bits(q)
+    out["s_c_bf16"] = bf16_bits(c)
+    for k in (1, 5, 10, 64, 100):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sc, ix, frac, pos = neg_mine.batch(q, c, 0, 3000, k)
+        out[f"s_k{k}_score"] = sc.numpy()
+        out[f"s_k{k}_idx"] = ix.numpy().astype(np.int32)
+    out["s_frac"] = frac.numpy()
+    out["s_pos"] = pos.numpy()
+    # two batches of the same data (idx offset path, neg_mine.py:23-24,32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, ix, frac, pos = neg_mine.batch(q, c, 300, 200, 10)
+    out["s_b300_score"], out["s_b300_idx"] = sc.numpy(), ix.numpy().astype(np.int32)
+    out["s_b300_frac"], out["s_b300_pos"] = frac.numpy(), pos.numpy()
+    # larger seed-defined case: inputs regenerated by the test from the seed
+    q, c = make_clustered(3000, 4000, 256, seed=77, n_centres=64)
+    q, c = q.to(torch.bfloat16).float(), c.to(torch.bfloat16).float()
+    with contextlib.redirect_stdout(io.StringIO()):
+        sc, ix, frac, pos = neg_mine.batch(q, c, 0, 3000, 10)
+    out["l_seed"] = np.int64(77)
+    out["l_score"], out["l_idx"] = sc.numpy(), ix.numpy().astype(np.int32)
+    out["l_frac"], out["l_pos"] = frac.numpy(), pos.numpy()
+    out["l_q_sum"] = q.double().sum().numpy()
+    out["l_c_sum"] = c.double().sum().numpy()
+    np.savez_compressed(os.path.join(OUT, "neg_mine_batch.npz"), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
+    abc_util, neg_mine = _ref()
+    torch.set_num_threads(4)
+    gen_loss(abc_util)
+    gen_neg_mine(neg_mine)
+    gen_gathered()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
