@@ -1,0 +1,136 @@
+/*
+ * abcsearch.h -- C ABI of libabcsearch.so (MI355X / gfx950 only).
+ *
+ * Exact similarity search over embeddings (score = Q.C^T, per-row top-k fused into the
+ * MFMA GEMM epilogue, optional per-row upper bound = the hard-negative rule) and the
+ * temperature-scaled, label-smoothed InfoNCE forward/backward.
+ *
+ * The reference (Ben-Schneider-code/vllm @ 2025-03-01) has no FFI layer: its boundary is a set of
+ * Python functions calling torch ops.  Each entry point below names the reference call site whose
+ * arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates, passes data_ptr());
+ *     the library borrows it for the enqueued work and never frees or retains it;
+ *   - matrices are row-major contiguous, base 16-byte aligned; d*sizeof(elem) must be a multiple
+ *     of 128 (bf16: d%64==0, int8: d%128==0, f32: d%32==0);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit device sync;
+ *   - return 0 = ok, negative = error (ABC_E_*); message via abc_last_error() (thread-local);
+ *   - no exceptions, no C++ types, no torch types cross this boundary.
+ */
+#ifndef ABCSEARCH_H
+#define ABCSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABC_OK 0
+#define ABC_E_INVALID (-1)   /* bad argument (shape, alignment, k, null pointer) */
+#define ABC_E_WORKSPACE (-2) /* workspace too small */
+#define ABC_E_HIP (-3)       /* HIP runtime error at enqueue time */
+
+#define ABC_DT_BF16 0
+#define ABC_DT_I8 1
+#define ABC_DT_F32 2
+
+#define ABC_MAX_K 128
+
+const char* abc_version(void);
+const char* abc_last_error(void);
+
+/* Bytes of device workspace abc_topk_* needs for this problem (0 on invalid arguments). */
+size_t abc_topk_workspace_bytes(int64_t nq, int64_t nc, int d, int k, int dtype);
+
+/*
+ * Exact top-k of q @ c^T per query row, best first; ties: larger score, then smaller index.
+ * Replaces  scores = query_stack @ candidate_stack.T; torch.topk(scores, k, dim=1)
+ *   evaluate/eval_mscoco.py:40-41 (same in eval_flickr30k.py:40-41, eval_vg_instruct.py, mmeb_*.py),
+ *   visualization/neg_mine.py:26-29,
+ * and, with upper_bound, the mask + sort of pretrain/create_negative_index.py:47-51
+ *   (scores[scores > thr] = -inf; argsort(descending)[:k]).
+ *
+ *   q [nq,d], c [nc,d]       inputs of the dtype in the name
+ *   upper_bound [nq] f32     nullable; scores strictly greater than upper_bound[i] are dropped
+ *   idx_offset               added to every returned index (global index of c's row 0 on a shard)
+ *   out_val [nq,k] f32       scores; missing entries (fewer than k survivors) = -inf
+ *   out_idx [nq,k] i64       indices; missing entries = -1
+ *   rank_ref [nq] f32 / out_rank [nq] i64   nullable pair; out_rank[i] = #{j : score_ij > rank_ref[i]}
+ *                            (visualization/neg_mine.py:37-38, the compare-count of batch())
+ *   workspace                >= abc_topk_workspace_bytes(...)
+ * The score matrix is never written to memory.
+ */
+int abc_topk_bf16(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k,
+                  const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                  const float* rank_ref, int64_t* out_rank,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k,
+                 const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                 const float* rank_ref, int64_t* out_rank,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* int8 with per-vector scales: score_ij = float(sum_k q_ik*c_jk) * (q_scale[i]*c_scale[j])
+ * (the build's int8 rule; no counterpart in the reference). */
+int abc_topk_i8(const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale,
+                int64_t nc, int d, int k,
+                const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                const float* rank_ref, int64_t* out_rank,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * out[i] = dot(q[i,:], c[i,:]) in fp32, i < n.  Replaces scores[idx] of
+ * pretrain/create_negative_index.py:48 and the bmm of visualization/neg_mine.py:32-35.
+ */
+int abc_rowdot_bf16(const void* q, const void* c, int64_t n, int d, float* out, void* stream);
+int abc_rowdot_f32(const void* q, const void* c, int64_t n, int d, float* out, void* stream);
+int abc_rowdot_i8(const void* q, const float* q_scale, const void* c, const float* c_scale, int64_t n, int d,
+                  float* out, void* stream);
+
+/*
+ * Merge `parts` sorted top-k lists per query into one (the cross-shard / cross-GPU merge after the
+ * all-gather; no counterpart in the reference, whose search is single-GPU).
+ *   vals [parts,nq,k] f32, idx [parts,nq,k] i64 (already global, -1 = missing) -> out_val/out_idx [nq,k]
+ */
+int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k,
+                   float* out_val, int64_t* out_idx, void* stream);
+
+/*
+ * Symmetric per-vector absmax int8 quantiser: scale = max|x|/127 (1 for an all-zero
+ * row), q = clamp(rint(x/scale), -127, 127), round-half-even.  x [n,d] f32 -> out_q [n,d] i8, out_scale [n].
+ */
+int abc_quantize_i8(const float* x, int64_t n, int d, int8_t* out_q, float* out_scale, void* stream);
+
+/* f32 -> bf16 (round-to-nearest-even) cast of an [n] array; embeddings saved as fp32 query.pt/cand.pt. */
+int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* stream);
+
+/*
+ * InfoNCE forward.  Replaces model/abc_util.py:47-54:
+ *   score = (q @ p^T) / temp; loss = cross_entropy(score, arange(B), label_smoothing=eps); argmax.
+ *   q [B,d] f32, p [C,d] f32 (C >= B; row i of p is the positive of query i)
+ *   out_loss [1] f32 (mean over rows), out_lse [B] f32 (logsumexp of score rows),
+ *   out_argmax [B] i32, workspace >= abc_infonce_workspace_bytes(B,C,d)
+ */
+size_t abc_infonce_workspace_bytes(int B, int C, int d);
+int abc_infonce_fwd(const float* q, const float* p, float inv_temp, float eps, int B, int C, int d,
+                    float* out_loss, float* out_lse, int32_t* out_argmax,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * InfoNCE backward (closed form of the autograd of model/abc_util.py:47-51):
+ *   g = (softmax(z) - [(1-eps)1{j=i} + eps/C]) * grad_out / B
+ *   dq = (g*inv_temp) p ; dp_local = ((g*inv_temp)^T q)[:local_rows] ; d_temp = -sum(g*s)*inv_temp^2
+ * Only the first local_rows rows of p receive a gradient (remote all-gathered blocks are constants,
+ * model/abc_util.py:19-21).  grad_out is a device scalar.
+ */
+int abc_infonce_bwd(const float* q, const float* p, const float* lse, float inv_temp, float eps,
+                    const float* grad_out, int B, int C, int d, int local_rows,
+                    float* dq, float* dp_local, float* d_temp,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABCSEARCH_H */

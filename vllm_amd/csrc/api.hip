@@ -1,0 +1,224 @@
+// C ABI of libabcsearch.so + the small streaming kernels (rowdot, quantise, cast).
+#include "common.h"
+#include "topk_sweep.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int abc_fail_hip(hipError_t e, const char* where) { return fail(ABC_E_HIP, "%s: %s", where, hipGetErrorString(e)); }
+int abc_fail_invalid(const char* msg) { return fail(ABC_E_INVALID, "%s", msg); }
+int abc_fail_ws(size_t need, size_t have) { return fail(ABC_E_WORKSPACE, "workspace too small: need %zu bytes, have %zu", need, have); }
+
+extern "C" const char* abc_version(void) { return "abcsearch 0.1.0 (gfx950)"; }
+extern "C" const char* abc_last_error(void) { return g_err; }
+
+static int elem_size(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 ? 1 : (dt == ABC_DT_F32 ? 4 : 0)); }
+
+static int check_common(int64_t nq, int64_t nc, int d, int k, int dt) {
+    if (elem_size(dt) == 0) return fail(ABC_E_INVALID, "unknown dtype %d", dt);
+    if (nq < 0 || nc < 0) return fail(ABC_E_INVALID, "negative row count");
+    if (d <= 0 || ((int64_t)d * elem_size(dt)) % 128 != 0)
+        return fail(ABC_E_INVALID, "d=%d: d*sizeof(elem) must be a positive multiple of 128 bytes", d);
+    if (k < 1 || k > ABC_MAX_K) return fail(ABC_E_INVALID, "k=%d out of range [1,%d]", k, ABC_MAX_K);
+    if (nc >= 0xFFFFFFFFll) return fail(ABC_E_INVALID, "nc=%lld exceeds 2^32-2 rows per call", (long long)nc);
+    return ABC_OK;
+}
+
+extern "C" size_t abc_topk_workspace_bytes(int64_t nq, int64_t nc, int d, int k, int dtype) {
+    if (check_common(nq, nc, d, k, dtype) != ABC_OK) return 0;
+    if (nq == 0 || nc == 0) return 16;
+    return sweep_workspace_bytes(nq, nc);
+}
+
+// fill [nq,k] outputs with (-inf, -1): the answer for an empty corpus
+__global__ void fill_empty_kernel(float* v, int64_t* ix, int64_t n, int64_t* rank, int64_t nq) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { v[i] = -INFINITY; ix[i] = -1; }
+    if (rank && i < nq) rank[i] = 0;
+}
+
+static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc,
+                      int d, int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                      const float* rank_ref, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(nq, nc, d, k, dt);
+    if (rc) return rc;
+    if (nq == 0) return ABC_OK;
+    if (!out_val || !out_idx) return fail(ABC_E_INVALID, "null output pointer");
+    if ((rank_ref == nullptr) != (out_rank == nullptr)) return fail(ABC_E_INVALID, "rank_ref and out_rank must be given together");
+    hipStream_t st = (hipStream_t)stream;
+    if (nc == 0) {
+        const int64_t n = nq * k;
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_val, out_idx, n, out_rank, nq);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "fill_empty");
+    }
+    if (!q || !c) return fail(ABC_E_INVALID, "null input pointer");
+    if (((uintptr_t)q | (uintptr_t)c) & 15) return fail(ABC_E_INVALID, "q and c must be 16-byte aligned");
+    if (dt == ABC_DT_I8 && (!qs || !cs)) return fail(ABC_E_INVALID, "int8 needs q_scale and c_scale");
+    const size_t need = sweep_workspace_bytes(nq, nc);
+    if (!ws || ws_bytes < need) return abc_fail_ws(need, ws_bytes);
+    if ((uintptr_t)ws & 15) return fail(ABC_E_INVALID, "workspace must be 16-byte aligned");
+    hipError_t he = hipSuccess;
+    rc = sweep_run(dt, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, st, &he);
+    if (rc == ABC_E_HIP) return abc_fail_hip(he, "topk sweep launch");
+    return rc;
+}
+
+extern "C" int abc_topk_bf16(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
+                             int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
+                             int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    return topk_entry(ABC_DT_BF16, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+}
+extern "C" int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
+                            int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
+                            int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    return topk_entry(ABC_DT_F32, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+}
+extern "C" int abc_topk_i8(const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc, int d,
+                           int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                           const float* rank_ref, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+}
+
+extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
+                              int64_t* out_idx, void* stream) {
+    if (parts < 1 || nq < 0 || k < 1 || k > ABC_MAX_K) return fail(ABC_E_INVALID, "bad merge shape parts=%d nq=%lld k=%d", parts, (long long)nq, k);
+    if (nq == 0) return ABC_OK;
+    if (!vals || !idx || !out_val || !out_idx) return fail(ABC_E_INVALID, "null pointer");
+    hipError_t he = hipSuccess;
+    int rc = merge_lists_run(vals, idx, parts, nq, k, out_val, out_idx, (hipStream_t)stream, &he);
+    if (rc == ABC_E_HIP) return abc_fail_hip(he, "merge launch");
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// rowdot: one wave per row, 16-byte loads, fp32 accumulate, fixed reduction order.
+template <int DT>
+__global__ __launch_bounds__(256) void rowdot_kernel(const char* __restrict__ q, const char* __restrict__ c,
+                                                     const float* __restrict__ qs, const float* __restrict__ cs,
+                                                     int64_t n, int rowbytes, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const v4i* a = (const v4i*)(q + row * rowbytes);
+    const v4i* b = (const v4i*)(c + row * rowbytes);
+    float accf = 0.f;
+    int acci = 0;
+    for (int i = lane; i < rowbytes / 16; i += 64) {
+        const v4i x = a[i], y = b[i];
+        if constexpr (DT == ABC_DT_BF16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t u = (uint32_t)x[j], w = (uint32_t)y[j];
+                accf = fmaf(__uint_as_float(u << 16), __uint_as_float(w << 16), accf);
+                accf = fmaf(__uint_as_float(u & 0xFFFF0000u), __uint_as_float(w & 0xFFFF0000u), accf);
+            }
+        } else if constexpr (DT == ABC_DT_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accf = fmaf(__int_as_float(x[j]), __int_as_float(y[j]), accf);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int b8 = 0; b8 < 4; ++b8) acci += (int)(int8_t)(x[j] >> (8 * b8)) * (int)(int8_t)(y[j] >> (8 * b8));
+            }
+        }
+    }
+    if constexpr (DT == ABC_DT_I8) {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) acci += __shfl_xor(acci, m, 64);
+        if (lane == 0) out[row] = (float)acci * (qs[row] * cs[row]);
+    } else {
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) accf += __shfl_xor(accf, m, 64);
+        if (lane == 0) out[row] = accf;
+    }
+}
+
+static int rowdot_entry(int dt, const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d,
+                        float* out, void* stream) {
+    if (elem_size(dt) == 0 || n < 0 || d <= 0 || ((int64_t)d * elem_size(dt)) % 16 != 0)
+        return fail(ABC_E_INVALID, "rowdot: bad shape n=%lld d=%d", (long long)n, d);
+    if (n == 0) return ABC_OK;
+    if (!q || !c || !out) return fail(ABC_E_INVALID, "null pointer");
+    if (((uintptr_t)q | (uintptr_t)c) & 15) return fail(ABC_E_INVALID, "q and c must be 16-byte aligned");
+    const int rowbytes = d * elem_size(dt);
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (dt == ABC_DT_BF16) hipLaunchKernelGGL(rowdot_kernel<ABC_DT_BF16>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
+    else if (dt == ABC_DT_F32) hipLaunchKernelGGL(rowdot_kernel<ABC_DT_F32>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
+    else hipLaunchKernelGGL(rowdot_kernel<ABC_DT_I8>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "rowdot launch");
+}
+extern "C" int abc_rowdot_bf16(const void* q, const void* c, int64_t n, int d, float* out, void* stream) {
+    return rowdot_entry(ABC_DT_BF16, q, nullptr, c, nullptr, n, d, out, stream);
+}
+extern "C" int abc_rowdot_f32(const void* q, const void* c, int64_t n, int d, float* out, void* stream) {
+    return rowdot_entry(ABC_DT_F32, q, nullptr, c, nullptr, n, d, out, stream);
+}
+extern "C" int abc_rowdot_i8(const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d, float* out,
+                             void* stream) {
+    if (!qs || !cs) return fail(ABC_E_INVALID, "int8 needs scales");
+    return rowdot_entry(ABC_DT_I8, q, qs, c, cs, n, d, out, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// int8 quantiser: one wave per row, two passes over the row (absmax, then quantise).
+__global__ __launch_bounds__(256) void quantize_i8_kernel(const float* __restrict__ x, int64_t n, int d,
+                                                          int8_t* __restrict__ oq, float* __restrict__ os) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* xr = x + row * d;
+    float amax = 0.f;
+    for (int i = lane; i < d; i += 64) amax = fmaxf(amax, fabsf(xr[i]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+    const float scale = amax > 0.f ? __fdiv_rn(amax, 127.0f) : 1.0f;
+    if (lane == 0) os[row] = scale;
+    for (int i = lane; i < d; i += 64) {
+        float r = rintf(__fdiv_rn(xr[i], scale));     // round-half-even, IEEE division as torch
+        r = fminf(fmaxf(r, -127.f), 127.f);
+        oq[row * d + i] = (int8_t)r;
+    }
+}
+extern "C" int abc_quantize_i8(const float* x, int64_t n, int d, int8_t* out_q, float* out_scale, void* stream) {
+    if (n < 0 || d <= 0) return fail(ABC_E_INVALID, "quantize: bad shape");
+    if (n == 0) return ABC_OK;
+    if (!x || !out_q || !out_scale) return fail(ABC_E_INVALID, "null pointer");
+    hipLaunchKernelGGL(quantize_i8_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d, out_q, out_scale);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "quantize launch");
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, int64_t n, uint16_t* __restrict__ o) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t u = __float_as_uint(x[i]);
+        uint32_t r;
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) r = (u >> 16) | 0x40u;            // NaN stays NaN
+        else r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                        // round-to-nearest-even
+        o[i] = (uint16_t)r;
+    }
+}
+extern "C" int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* stream) {
+    if (n < 0) return fail(ABC_E_INVALID, "cast: negative n");
+    if (n == 0) return ABC_OK;
+    if (!x || !out_bf16) return fail(ABC_E_INVALID, "null pointer");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, (uint16_t*)out_bf16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "cast launch");
+}

@@ -1,0 +1,41 @@
+// Internal interface of the fused score-GEMM + top-k sweep (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/abcsearch.h"
+
+#define CAND_CAP 256   // candidate-list capacity per (list set, query): 2 KiB of 8-byte keys
+
+struct SweepParams {
+    const char* q;          // [nq, rowbytes] queries of this launch
+    const char* c;          // [nc, rowbytes] corpus
+    int64_t nq, nc;
+    int rowbytes;           // d * sizeof(elem), multiple of 128
+    int nk;                 // rowbytes / 128 K-steps per tile
+    int k;
+    int n_qblocks;          // ceil(nq / 256) of this launch
+    int n_splits;           // corpus splits; grid = n_qblocks * n_splits
+    int n_tiles;            // ceil(nc / 256)
+    int64_t nq_pad;         // list stride between list sets (queries per launch, padded)
+    const float* ub;        // nullable [nq]
+    const float* q_scale;   // int8 only
+    const float* c_scale;   // int8 only
+    const float* rank_ref;  // COUNT only
+    uint64_t* cand;         // [2*n_splits][nq_pad][CAND_CAP] packed keys
+    uint32_t* rank_part;    // [2*n_splits][nq_pad]
+};
+
+struct SweepPlan {
+    int n_tiles;
+    int qblocks_per_launch;
+    int n_splits;
+    int64_t nq_pad;
+};
+
+void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl);
+size_t sweep_workspace_bytes(int64_t nq, int64_t nc);
+int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
+              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+              const float* rank_ref, int64_t* out_rank, void* workspace, hipStream_t st, hipError_t* herr);
+int merge_lists_run(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
+                    int64_t* out_idx, hipStream_t st, hipError_t* herr);

@@ -1,0 +1,488 @@
+// Fused score-GEMM + running top-k sweep for gfx950 (MI355X).
+//
+// One workgroup (8 waves, 512 threads) owns a block of 256 queries and a contiguous range of
+// 256-row corpus tiles (a "split").  For each tile it contracts the 256x256 score tile on the
+// matrix cores (corpus rows on the MFMA row axis, queries on the lane/column axis) and then filters
+// the accumulators, still in registers, against each query's running threshold.  Survivors are
+// appended to that query's candidate list in the workspace; a full list is compacted (wave-wide
+// bitonic sort, keep the best k, raise the threshold).  The score matrix never exists in memory.
+//
+// Staging: both operand tiles of a K-step (256 rows x 128 bytes each) go global -> LDS with
+// buffer_load ... lds (no VGPR round trip), double-buffered, one barrier per K-step.  LDS rows are
+// 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE address and on the
+// fragment read so that ds_read_b128 is bank-conflict free (LDS-DMA destinations are lane-linear).
+#include "common.h"
+#include "topk_sweep.h"
+
+#define TILE 256
+#define ROWB 128
+#define STAGE_BYTES (TILE * ROWB)          // one operand, one K-step: 32 KiB
+#define LDS_BYTES (4 * STAGE_BYTES)        // 2 buffers x 2 operands: 128 KiB
+
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct Acc;
+template <> struct Acc<ABC_DT_BF16> { typedef v16f type; };
+template <> struct Acc<ABC_DT_F32> { typedef v16f type; };
+template <> struct Acc<ABC_DT_I8> { typedef v16i type; };
+
+template <int DT>
+__device__ __forceinline__ void mma_step(typename Acc<DT>::type& acc, const v4i& a, const v4i& b) {
+    if constexpr (DT == ABC_DT_BF16) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8s, a), __builtin_bit_cast(v8s, b), acc, 0, 0, 0);
+    } else if constexpr (DT == ABC_DT_I8) {
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc, 0, 0, 0);
+    } else {
+        // f32: each lane holds 4 consecutive k of its row; one 32x32x2 MFMA per element.  The k order
+        // (chunk 2s+h, element t) is the same permutation for A and B.
+        const v4f af = __builtin_bit_cast(v4f, a), bf = __builtin_bit_cast(v4f, b);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[t], acc, 0, 0, 0);
+    }
+}
+
+// Issue the LDS-DMA loads of one K-step (both operands) into stage buffer `buf`.
+__device__ __forceinline__ void stage_issue(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rq, char* smem, int buf,
+                                            int wave, const int (&voff)[4], int soff) {
+    char* dst = smem + buf * (2 * STAGE_BYTES) + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, LDS_PTR(dst + i * 1024), 16, voff[i], soff, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(dst + STAGE_BYTES + i * 1024), 16, voff[i], soff, 0, 0);
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, uint32_t bytes) {
+    // wave-uniform by construction (kernel arguments and blockIdx only); readfirstlane makes it provable
+    const uint64_t b = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint32_t n = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compaction of one query's candidate list: sort (desc), keep the best k, return the new threshold.
+// Called by the whole wave (uniform).  `buf` is wave-uniform.
+__device__ __forceinline__ void compact_list(uint64_t* buf, int n, int k, int lane, float& new_thr, int& new_cnt,
+                                             bool finalize) {
+    uint64_t key[CAND_CAP / 64];
+#pragma unroll
+    for (int e = 0; e < CAND_CAP / 64; ++e) {
+        const int i = e * 64 + lane;
+        key[e] = (i < n) ? buf[i] : 0ull;
+    }
+    wave_sort_desc<CAND_CAP / 64>(key, lane);
+    const int keep = n < k ? n : k;
+#pragma unroll
+    for (int e = 0; e < CAND_CAP / 64; ++e) {
+        const int i = e * 64 + lane;
+        if (i < keep) buf[i] = key[e];
+        else if (finalize && i < k) buf[i] = 0ull;
+    }
+    // value at rank k-1 becomes the threshold once the list is full
+    uint64_t kth = 0;
+#pragma unroll
+    for (int e = 0; e < CAND_CAP / 64; ++e)
+        if (e == ((k - 1) >> 6)) kth = key[e];
+    kth = shfl_u64(kth, (k - 1) & 63);
+    new_cnt = keep;
+    new_thr = (n >= k) ? key_val(kth) : -INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int DT, bool COUNT>
+__global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Acc<DT>::type acc_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;        // corpus half of the tile (rows wm*128 ..)
+    const int wn = wave & 3;         // query quarter of the tile (cols wn*64 ..)
+    const int h = lane >> 5;
+    const int l31 = lane & 31;
+
+    // ---- workgroup -> (query block, split); XCD-aware: blocks with equal id%8 share an L2 ----------
+    int qb, split;
+    {
+        const int id = blockIdx.x;
+        if ((p.n_qblocks & 7) == 0) {
+            const int per = p.n_qblocks >> 3;
+            const int x = id & 7, j = id >> 3;
+            qb = x * per + (j % per);
+            split = j / per;
+        } else {
+            qb = id % p.n_qblocks;
+            split = id / p.n_qblocks;
+        }
+    }
+    const int64_t qrow0 = (int64_t)qb * TILE;
+    const int t_begin = (int)(((int64_t)split * p.n_tiles) / p.n_splits);
+    const int t_end = (int)(((int64_t)(split + 1) * p.n_tiles) / p.n_splits);
+    const int nk = p.nk;
+    const int rowbytes = p.rowbytes;
+
+    // ---- staging addresses -----------------------------------------------------------------------
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + i * 8 + (lane >> 3);
+        const int swz = (i * 4 + (lane >> 4)) & 7;
+        voff[i] = row * rowbytes + (((lane & 7) ^ swz) << 4);
+    }
+    const int64_t q_rows_left = p.nq - qrow0;
+    const uint32_t q_bytes = (uint32_t)((q_rows_left < TILE ? q_rows_left : TILE) * rowbytes);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + qrow0 * rowbytes, q_bytes);
+
+    // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>1)&7)
+    const int swz_r = (l31 >> 1) & 7;
+    int xs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) xs[s] = l31 * ROWB + (((2 * s + h) ^ swz_r) << 4);
+    const int a_base = wm * 128 * ROWB;                   // corpus operand, rows wm*128 + mb*32 + l31
+    const int b_base = STAGE_BYTES + wn * 64 * ROWB;      // query operand, rows wn*64 + nb*32 + l31
+
+    // ---- per-query running state (lanes l and l+32 hold the same query and the same values) --------
+    const int ss = split * 2 + wm;                        // candidate-list set of this wave
+    float thr[2], ub[2], qsc[2], rref[2];
+    int cnt[2];
+    uint32_t rank[2];
+    int64_t qrow[2];
+    uint64_t* cbuf[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        qrow[nb] = qrow0 + wn * 64 + nb * 32 + l31;
+        const bool valid = qrow[nb] < p.nq;
+        thr[nb] = valid ? -INFINITY : INFINITY;           // invalid query rows never pass
+        ub[nb] = (valid && p.ub) ? p.ub[qrow[nb]] : INFINITY;
+        qsc[nb] = (DT == ABC_DT_I8 && valid) ? p.q_scale[qrow[nb]] : 1.0f;
+        rref[nb] = (COUNT && valid) ? p.rank_ref[qrow[nb]] : INFINITY;
+        cnt[nb] = 0;
+        rank[nb] = 0;
+        cbuf[nb] = p.cand + ((int64_t)ss * p.nq_pad + (qrow[nb] < p.nq_pad ? qrow[nb] : 0)) * CAND_CAP;
+    }
+
+    acc_t acc[4][2];
+
+    // ---- software pipeline over (tile, kstep) -----------------------------------------------------
+    auto corpus_rsrc = [&](int tile) {
+        const int64_t r0 = (int64_t)tile * TILE;
+        const int64_t left = p.nc - r0;
+        return make_rsrc(p.c + r0 * rowbytes, (uint32_t)((left < TILE ? left : TILE) * rowbytes));
+    };
+
+    if (t_begin < t_end) {
+        __amdgpu_buffer_rsrc_t rc = corpus_rsrc(t_begin);
+        stage_issue(rc, rq, smem, 0, wave, voff, 0);
+        int cur = 0;
+        for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0;
+
+            __amdgpu_buffer_rsrc_t rc_next = rc;
+            if (tile + 1 < t_end) rc_next = corpus_rsrc(tile + 1);
+
+            for (int ks = 0; ks < nk; ++ks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (ks + 1 < nk) stage_issue(rc, rq, smem, cur ^ 1, wave, voff, (ks + 1) * ROWB);
+                else if (tile + 1 < t_end) stage_issue(rc_next, rq, smem, cur ^ 1, wave, voff, 0);
+
+                const char* sb = smem + cur * (2 * STAGE_BYTES);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    v4i a[4], b[2];
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) a[mb] = *(const v4i*)(sb + a_base + mb * 32 * ROWB + xs[s]);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) b[nb] = *(const v4i*)(sb + b_base + nb * 32 * ROWB + xs[s]);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) mma_step<DT>(acc[mb][nb], a[mb], b[nb]);
+                }
+                cur ^= 1;
+            }
+            rc = rc_next;
+
+            // ---- epilogue: filter the 128x64 accumulator block of this wave against the thresholds ----
+            const int64_t crow_tile = (int64_t)tile * TILE + wm * 128;
+            const bool partial = crow_tile + 128 > p.nc;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const uint32_t cbase = (uint32_t)(crow_tile + mb * 32 + 4 * h);
+                float csc[16];
+                if constexpr (DT == ABC_DT_I8) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
+                        csc[r] = (ci < (uint32_t)p.nc) ? p.c_scale[ci] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if constexpr (DT == ABC_DT_I8) v[r] = (float)acc[mb][nb][r] * (qsc[nb] * csc[r]);
+                        else v[r] = acc[mb][nb][r];
+                    }
+                    if constexpr (COUNT) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
+                            rank[nb] += (v[r] > rref[nb] && (!partial || ci < (uint32_t)p.nc)) ? 1u : 0u;
+                        }
+                    }
+                    // quick reject: nothing in this 32x32 block beats any threshold
+                    float m = v[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
+                    if (__ballot(m > thr[nb]) == 0ull) continue;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
+                        bool pass = (v[r] > thr[nb]) && !(v[r] > ub[nb]);
+                        if (partial) pass = pass && (ci < (uint32_t)p.nc);
+                        if (__ballot(pass) != 0ull) {
+                            const int mine = pass ? 1 : 0;
+                            const int other = __shfl_xor(mine, 32, 64);
+                            const int pos = cnt[nb] + (h ? other : 0);
+                            if (pass) cbuf[nb][pos] = make_key(v[r], ci);
+                            cnt[nb] += mine + other;
+                        }
+                    }
+                    // a list that could overflow during the next block is compacted now
+                    uint64_t need = __ballot(cnt[nb] > CAND_CAP - 32) & 0xFFFFFFFFull;
+                    if (need) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        while (need) {
+                            const int j = __builtin_ctzll(need);
+                            need &= need - 1;
+                            const int n = __shfl(cnt[nb], j, 64);
+                            uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + (qrow0 + wn * 64 + nb * 32 + j)) * CAND_CAP;
+                            float nt; int nc2;
+                            compact_list(bj, n, p.k, lane, nt, nc2, false);
+                            if (l31 == j) { thr[nb] = nt; cnt[nb] = nc2; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- end of the sweep: sort every list, pad to k, publish the rank counts -----------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        for (int j = 0; j < 32; ++j) {
+            const int64_t qr = qrow0 + wn * 64 + nb * 32 + j;
+            if (qr >= p.nq) break;                         // uniform
+            const int n = __shfl(cnt[nb], j, 64);
+            uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + qr) * CAND_CAP;
+            float nt; int nc2;
+            compact_list(bj, n, p.k, lane, nt, nc2, true);
+        }
+        if constexpr (COUNT) {
+            const uint32_t tot = rank[nb] + __shfl_xor(rank[nb], 32, 64);
+            if (h == 0 && qrow[nb] < p.nq) p.rank_part[(int64_t)ss * p.nq_pad + qrow[nb]] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge the 2*n_splits sorted lists of each query into out_val/out_idx.  One wave per query.
+template <int EK>
+__global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, int n_lists,
+                                                                int64_t nq, int64_t nq_pad, int k, int64_t idx_offset,
+                                                                float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                                const uint32_t* __restrict__ rank_part,
+                                                                int64_t* __restrict__ out_rank) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qr >= nq) return;
+    uint64_t best[EK];
+#pragma unroll
+    for (int e = 0; e < EK; ++e) best[e] = 0ull;
+    for (int l = 0; l < n_lists; ++l) {
+        const uint64_t* src = cand + ((int64_t)l * nq_pad + qr) * CAND_CAP;
+        uint64_t nw[EK];
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const int i = e * 64 + lane;
+            nw[e] = (i < k) ? src[i] : 0ull;
+        }
+        // best (desc) vs reversed new list: element-wise max is bitonic and holds the top 64*EK
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const uint64_t rev = shfl_u64(nw[EK - 1 - e], 63 - lane);
+            best[e] = best[e] > rev ? best[e] : rev;
+        }
+        wave_bitonic_merge_desc<EK>(best, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < EK; ++e) {
+        const int i = e * 64 + lane;
+        if (i < k) {
+            const uint64_t kk = best[e];
+            out_val[qr * k + i] = kk ? key_val(kk) : -INFINITY;
+            out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) + idx_offset : -1;
+        }
+    }
+    if (out_rank != nullptr && lane == 0) {
+        int64_t tot = 0;
+        for (int l = 0; l < n_lists; ++l) tot += rank_part[(int64_t)l * nq_pad + qr];
+        out_rank[qr] = tot;
+    }
+}
+
+// Merge `parts` external (val, idx) lists per query -- the cross-shard / cross-GPU merge.
+template <int EK>
+__global__ __launch_bounds__(256) void topk_merge_lists_kernel(const float* __restrict__ vals, const int64_t* __restrict__ idx,
+                                                               int parts, int64_t nq, int k,
+                                                               float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qr >= nq) return;
+    uint64_t best[EK];
+#pragma unroll
+    for (int e = 0; e < EK; ++e) best[e] = 0ull;
+    for (int l = 0; l < parts; ++l) {
+        const int64_t base = ((int64_t)l * nq + qr) * k;
+        uint64_t nw[EK];
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const int i = e * 64 + lane;
+            uint64_t kk = 0ull;
+            if (i < k) {
+                const int64_t ix = idx[base + i];
+                if (ix >= 0) kk = make_key(vals[base + i], (uint32_t)ix);
+            }
+            nw[e] = kk;
+        }
+        // inputs are sorted by (value desc, index asc) == key desc, holes (key 0) last
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const uint64_t rev = shfl_u64(nw[EK - 1 - e], 63 - lane);
+            best[e] = best[e] > rev ? best[e] : rev;
+        }
+        wave_bitonic_merge_desc<EK>(best, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < EK; ++e) {
+        const int i = e * 64 + lane;
+        if (i < k) {
+            const uint64_t kk = best[e];
+            out_val[qr * k + i] = kk ? key_val(kk) : -INFINITY;
+            out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) : -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------
+static int elem_bytes(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 ? 1 : 4); }
+
+void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl) {
+    pl->n_tiles = (int)((nc + TILE - 1) / TILE);
+    const int64_t qblocks_total = (nq + TILE - 1) / TILE;
+    pl->qblocks_per_launch = (int)(qblocks_total < 32 ? qblocks_total : 32);
+    int s = 256 / pl->qblocks_per_launch;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    if (s > pl->n_tiles) s = pl->n_tiles;
+    if (s < 1) s = 1;
+    pl->n_splits = s;
+    pl->nq_pad = (int64_t)pl->qblocks_per_launch * TILE;
+}
+
+size_t sweep_workspace_bytes(int64_t nq, int64_t nc) {
+    SweepPlan pl;
+    sweep_plan(nq, nc, &pl);
+    const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
+    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t);
+}
+
+template <int DT, bool COUNT>
+static hipError_t launch_sweep(const SweepParams& p, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = topk_sweep_kernel<DT, COUNT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, st, p);
+    return hipGetLastError();
+}
+
+int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
+              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+              const float* rank_ref, int64_t* out_rank, void* workspace, hipStream_t st, hipError_t* herr) {
+    SweepPlan pl;
+    sweep_plan(nq, nc, &pl);
+    const int rowbytes = d * elem_bytes(dt);
+    const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
+    uint64_t* cand = (uint64_t*)workspace;
+    uint32_t* rank_part = (uint32_t*)(cand + lists * CAND_CAP);
+    const bool count = rank_ref != nullptr && out_rank != nullptr;
+
+    for (int64_t q0 = 0; q0 < nq; q0 += pl.nq_pad) {
+        const int64_t nq_l = (nq - q0 < pl.nq_pad) ? nq - q0 : pl.nq_pad;
+        SweepParams p;
+        p.q = (const char*)q + q0 * rowbytes;
+        p.c = (const char*)c;
+        p.nq = nq_l;
+        p.nc = nc;
+        p.rowbytes = rowbytes;
+        p.nk = rowbytes / ROWB;
+        p.k = k;
+        p.n_qblocks = (int)((nq_l + TILE - 1) / TILE);
+        p.n_splits = pl.n_splits;
+        p.n_tiles = pl.n_tiles;
+        p.nq_pad = pl.nq_pad;
+        p.ub = upper_bound ? upper_bound + q0 : nullptr;
+        p.q_scale = q_scale ? q_scale + q0 : nullptr;
+        p.c_scale = c_scale;
+        p.rank_ref = count ? rank_ref + q0 : nullptr;
+        p.cand = cand;
+        p.rank_part = rank_part;
+        const int grid = p.n_qblocks * p.n_splits;
+        hipError_t e;
+        if (dt == ABC_DT_BF16) e = count ? launch_sweep<ABC_DT_BF16, true>(p, grid, st) : launch_sweep<ABC_DT_BF16, false>(p, grid, st);
+        else if (dt == ABC_DT_I8) e = count ? launch_sweep<ABC_DT_I8, true>(p, grid, st) : launch_sweep<ABC_DT_I8, false>(p, grid, st);
+        else e = count ? launch_sweep<ABC_DT_F32, true>(p, grid, st) : launch_sweep<ABC_DT_F32, false>(p, grid, st);
+        if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
+        const int mgrid = (int)((nq_l + 3) / 4);
+        if (k <= 64)
+            hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, 2 * pl.n_splits, nq_l,
+                               pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
+                               count ? out_rank + q0 : nullptr);
+        else
+            hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, 2 * pl.n_splits, nq_l,
+                               pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
+                               count ? out_rank + q0 : nullptr);
+        e = hipGetLastError();
+        if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
+    }
+    return ABC_OK;
+}
+
+int merge_lists_run(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
+                    int64_t* out_idx, hipStream_t st, hipError_t* herr) {
+    const int mgrid = (int)((nq + 3) / 4);
+    if (mgrid == 0) return ABC_OK;
+    if (k <= 64) hipLaunchKernelGGL(topk_merge_lists_kernel<1>, dim3(mgrid), dim3(256), 0, st, vals, idx, parts, nq, k, out_val, out_idx);
+    else hipLaunchKernelGGL(topk_merge_lists_kernel<2>, dim3(mgrid), dim3(256), 0, st, vals, idx, parts, nq, k, out_val, out_idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
+    return ABC_OK;
+}
