@@ -258,21 +258,27 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                             cnt[nb] += mine + other;
                         }
                     }
-                    // a list that could overflow during the next block is compacted now
-                    uint64_t need = __ballot(cnt[nb] > CAND_CAP - 32) & 0xFFFFFFFFull;
-                    if (need) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        while (need) {
-                            const int j = __builtin_ctzll(need);
-                            need &= need - 1;
-                            const int n = __shfl(cnt[nb], j, 64);
-                            uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + (qrow0 + wn * 64 + nb * 32 + j)) * CAND_CAP;
-                            float nt; int nc2;
-                            compact_list(bj, n, p.k, lane, nt, nc2, false);
-                            if (l31 == j) { thr[nb] = nt; cnt[nb] = nc2; }
+                }
+            }
+            // ---- once per tile: compact every list that could overflow during the next tile ------------
+            // (a wave appends at most 128 entries per query and tile; CAND_TRIG = CAND_CAP - 128)
+            {
+                uint64_t need = (__ballot(cnt[0] > CAND_TRIG) & 0xFFFFFFFFull) | (__ballot(cnt[1] > CAND_TRIG) << 32);
+                if (need) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    while (need) {
+                        const int jb = __builtin_ctzll(need);
+                        need &= need - 1;
+                        const int nbq = jb >> 5, j = jb & 31;
+                        const int n = __shfl(nbq ? cnt[1] : cnt[0], j, 64);
+                        uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + (qrow0 + wn * 64 + nbq * 32 + j)) * CAND_CAP;
+                        float nt; int nc2;
+                        compact_list(bj, n, p.k, lane, nt, nc2, false);
+                        if (l31 == j) {
+                            if (nbq) { thr[1] = nt; cnt[1] = nc2; } else { thr[0] = nt; cnt[0] = nc2; }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 }
             }
         }
