@@ -38,6 +38,7 @@ extern "C" {
 #define ABC_DT_F32 2
 
 #define ABC_MAX_K 128
+#define ABC_NO_SELF INT64_MIN
 
 const char* abc_version(void);
 const char* abc_last_error(void);
@@ -58,19 +59,21 @@ size_t abc_topk_workspace_bytes(int64_t nq, int64_t nc, int d, int k, int dtype)
  *   idx_offset               added to every returned index (global index of c's row 0 on a shard)
  *   out_val [nq,k] f32       scores; missing entries (fewer than k survivors) = -inf
  *   out_idx [nq,k] i64       indices; missing entries = -1
- *   rank_ref [nq] f32 / out_rank [nq] i64   nullable pair; out_rank[i] = #{j : score_ij > rank_ref[i]}
- *                            (visualization/neg_mine.py:37-38, the compare-count of batch())
+ *   rank_ref [nq] f32 / out_rank [nq] i64   nullable pair; out_rank[i] = #{j != i + rank_self_offset :
+ *                            score_ij > rank_ref[i]} (visualization/neg_mine.py:37-38, the compare-count of
+ *                            batch()); column i + rank_self_offset is query i's own positive, whose score
+ *                            equals rank_ref[i] up to rounding and is never counted; ABC_NO_SELF = none
  *   workspace                >= abc_topk_workspace_bytes(...)
  * The score matrix is never written to memory.
  */
 int abc_topk_bf16(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k,
                   const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
-                  const float* rank_ref, int64_t* out_rank,
+                  const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k,
                  const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
-                 const float* rank_ref, int64_t* out_rank,
+                 const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank,
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* int8 with per-vector scales: score_ij = float(sum_k q_ik*c_jk) * (q_scale[i]*c_scale[j])
@@ -78,7 +81,7 @@ int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, in
 int abc_topk_i8(const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale,
                 int64_t nc, int d, int k,
                 const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
-                const float* rank_ref, int64_t* out_rank,
+                const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank,
                 void* workspace, size_t workspace_bytes, void* stream);
 
 /*
@@ -111,21 +114,23 @@ int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* stream);
  * InfoNCE forward.  Replaces model/abc_util.py:47-54:
  *   score = (q @ p^T) / temp; loss = cross_entropy(score, arange(B), label_smoothing=eps); argmax.
  *   q [B,d] f32, p [C,d] f32 (C >= B; row i of p is the positive of query i)
+ *   temp [1] f32 DEVICE scalar (Temperature.temp, model/modeling_abc.py:36-43; score = s / temp)
  *   out_loss [1] f32 (mean over rows), out_lse [B] f32 (logsumexp of score rows),
  *   out_argmax [B] i32, workspace >= abc_infonce_workspace_bytes(B,C,d)
  */
 size_t abc_infonce_workspace_bytes(int B, int C, int d);
-int abc_infonce_fwd(const float* q, const float* p, float inv_temp, float eps, int B, int C, int d,
+int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
                     float* out_loss, float* out_lse, int32_t* out_argmax,
                     void* workspace, size_t workspace_bytes, void* stream);
 /*
  * InfoNCE backward (closed form of the autograd of model/abc_util.py:47-51):
  *   g = (softmax(z) - [(1-eps)1{j=i} + eps/C]) * grad_out / B
- *   dq = (g*inv_temp) p ; dp_local = ((g*inv_temp)^T q)[:local_rows] ; d_temp = -sum(g*s)*inv_temp^2
+ *   dq = (g/temp) p ; dp_local = ((g/temp)^T q)[:local_rows] ; d_temp = -sum(g*s)/temp^2
+ * `workspace` must be the buffer abc_infonce_fwd was given for the same (q, p): it carries the logits.
  * Only the first local_rows rows of p receive a gradient (remote all-gathered blocks are constants,
  * model/abc_util.py:19-21).  grad_out is a device scalar.
  */
-int abc_infonce_bwd(const float* q, const float* p, const float* lse, float inv_temp, float eps,
+int abc_infonce_bwd(const float* q, const float* p, const float* lse, const float* temp, float eps,
                     const float* grad_out, int B, int C, int d, int local_rows,
                     float* dq, float* dp_local, float* d_temp,
                     void* workspace, size_t workspace_bytes, void* stream);

@@ -1,0 +1,125 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, argument errors are
+reported without touching a GPU, the product path refuses to run without one, and the sharded
+exchange logic (world_size 2, gloo) is correct when fed an exact checker in place of the kernels."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vllm_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "abcsearch.h")).read()
+    declared = set(re.findall(r"\b(abc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.abc_version()
+
+
+def test_argument_errors_without_gpu():
+    from vllm_amd import _lib
+    lib = _lib.load()
+    assert lib.abc_topk_workspace_bytes(10, 10, 72, 5, _lib.DT_BF16) == 0          # d*2 % 128 != 0
+    assert b"multiple of 128" in lib.abc_last_error()
+    assert lib.abc_topk_workspace_bytes(10, 10, 64, 129, _lib.DT_BF16) == 0        # k too large
+    assert lib.abc_topk_workspace_bytes(8192, 3_300_000, 4096, 64, _lib.DT_BF16) > 0
+    assert lib.abc_topk_bf16(None, 4, None, 4, 64, 5, None, 0, None, None, None, _lib.NO_SELF, None, None, 0, None) == -1
+    assert lib.abc_topk_merge(None, None, 0, 4, 5, None, None, None) == -1
+    assert lib.abc_infonce_workspace_bytes(8, 4, 64) == 0                           # C < B
+    assert lib.abc_infonce_workspace_bytes(128, 1024, 4096) > 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    from vllm_amd import kernels, _lib, loss
+    q = torch.zeros((4, 64), dtype=torch.bfloat16)
+    with pytest.raises(_lib.AbcError):
+        kernels.topk(q, q, 2)
+    with pytest.raises(_lib.AbcError):
+        loss.compute_contrastive_loss(torch.zeros(4, 64), torch.zeros(4, 64), loss.Temperature())
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "vllm_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_shard_bounds_cover():
+    from vllm_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 3_300_000):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+class _Emb:
+    """CPU stand-in for search.Embeddings in the exchange test (rows(), shape, data)."""
+
+    def __init__(self, x):
+        self.data, self.scale = x, None
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def rows(self, lo, hi):
+        return _Emb(self.data[lo:hi])
+
+
+def _worker(rank, world, port, ret):
+    import oracle
+    from vllm_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q, c = oracle.make_clustered(40, 301, 64, seed=6, n_centres=4)
+    c[100] = c[200]                                                     # a tie across two shards
+    lo, hi = parallel.shard_bounds(c.shape[0], world, rank)
+
+    def _topk(qe, ce, k, ub, off):
+        v, i = oracle.topk_ref(qe.data, ce.data, k, upper_bound=ub)
+        return v, torch.where(i >= 0, i + off, i)
+
+    def _merge(vals, idx):
+        parts, nq, k = vals.shape
+        v = vals.permute(1, 0, 2).reshape(nq, parts * k)
+        i = idx.permute(1, 0, 2).reshape(nq, parts * k)
+        key_i = torch.where(i >= 0, i, torch.full_like(i, 1 << 40))
+        o1 = torch.argsort(key_i, dim=1, stable=True)
+        v, i = torch.gather(v, 1, o1), torch.gather(i, 1, o1)
+        o2 = torch.argsort(v, dim=1, descending=True, stable=True)
+        return torch.gather(v, 1, o2)[:, :k].contiguous(), torch.gather(i, 1, o2)[:, :k].contiguous()
+
+    be = parallel.Backend(topk=_topk, rowdot=lambda a, b: (a.data * b.data).sum(-1), merge=_merge)
+    sc = parallel.ShardedCorpus(_Emb(c[lo:hi]), lo, c.shape[0], backend=be)
+    idx, vals, s_pos = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3)
+    ret[rank] = (idx, vals, s_pos)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_mining_exchange_gloo(world):
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29650 + world, ret), nprocs=world, join=True)
+    q, c = oracle.make_clustered(40, 301, 64, seed=6, n_centres=4)
+    c[100] = c[200]
+    s_pos = (q * c[3:43]).sum(-1)
+    rv, ri = oracle.topk_ref(q, c, 16, upper_bound=s_pos * 0.95)
+    for r in range(world):
+        idx, vals, sp = ret[r]
+        assert torch.allclose(sp, s_pos, atol=1e-6)
+        assert torch.equal(idx, ri) and torch.allclose(vals, rv, atol=1e-6)      # replicated and exact on every rank

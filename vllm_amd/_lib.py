@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libabcsearch.so")
 
 DT_BF16, DT_I8, DT_F32 = 0, 1, 2
 MAX_K = 128
+NO_SELF = -(1 << 63)
 
 _vp, _i64, _int, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
 
@@ -20,9 +21,9 @@ SIGNATURES = {
     "abc_version": (C.c_char_p, []),
     "abc_last_error": (C.c_char_p, []),
     "abc_topk_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
-    "abc_topk_bf16": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "abc_topk_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "abc_topk_i8": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_topk_bf16": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "abc_topk_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "abc_topk_i8": (_int, [_vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "abc_rowdot_bf16": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "abc_rowdot_f32": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "abc_rowdot_i8": (_int, [_vp, _vp, _vp, _vp, _i64, _int, _vp, _vp]),
@@ -30,8 +31,8 @@ SIGNATURES = {
     "abc_quantize_i8": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "abc_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),
     "abc_infonce_workspace_bytes": (_sz, [_int, _int, _int]),
-    "abc_infonce_fwd": (_int, [_vp, _vp, _f32, _f32, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "abc_infonce_bwd": (_int, [_vp, _vp, _vp, _f32, _f32, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_infonce_fwd": (_int, [_vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_infonce_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

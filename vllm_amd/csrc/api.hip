@@ -48,7 +48,7 @@ __global__ void fill_empty_kernel(float* v, int64_t* ix, int64_t n, int64_t* ran
 
 static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc,
                       int d, int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
-                      const float* rank_ref, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+                      const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(nq, nc, d, k, dt);
     if (rc) return rc;
     if (nq == 0) return ABC_OK;
@@ -68,25 +68,26 @@ static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const 
     if (!ws || ws_bytes < need) return abc_fail_ws(need, ws_bytes);
     if ((uintptr_t)ws & 15) return fail(ABC_E_INVALID, "workspace must be 16-byte aligned");
     hipError_t he = hipSuccess;
-    rc = sweep_run(dt, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, st, &he);
+    rc = sweep_run(dt, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, st, &he);
     if (rc == ABC_E_HIP) return abc_fail_hip(he, "topk sweep launch");
     return rc;
 }
 
 extern "C" int abc_topk_bf16(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
                              int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
-                             int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
-    return topk_entry(ABC_DT_BF16, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+                             int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    return topk_entry(ABC_DT_BF16, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 extern "C" int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
                             int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
-                            int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
-    return topk_entry(ABC_DT_F32, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+                             int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
+    return topk_entry(ABC_DT_F32, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 extern "C" int abc_topk_i8(const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc, int d,
                            int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
-                           const float* rank_ref, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
-    return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, out_rank, ws, ws_bytes, stream);
+                           const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes,
+                           void* stream) {
+    return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 
 extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,

@@ -22,6 +22,7 @@ struct SweepParams {
     const float* q_scale;   // int8 only
     const float* c_scale;   // int8 only
     const float* rank_ref;  // COUNT only
+    int64_t rank_excl;      // COUNT only: column (query row + rank_excl) is not counted
     uint64_t* cand;         // [2*n_splits][nq_pad][CAND_CAP] packed keys
     uint32_t* rank_part;    // [2*n_splits][nq_pad]
 };
@@ -37,6 +38,7 @@ void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl);
 size_t sweep_workspace_bytes(int64_t nq, int64_t nc);
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
               int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
-              const float* rank_ref, int64_t* out_rank, void* workspace, hipStream_t st, hipError_t* herr);
+              const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
+              hipError_t* herr);
 int merge_lists_run(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
                     int64_t* out_idx, hipStream_t st, hipError_t* herr);

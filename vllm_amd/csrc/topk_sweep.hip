@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     const int ss = split * 2 + wm;                        // candidate-list set of this wave
     float thr[2], ub[2], qsc[2], rref[2];
     int cnt[2];
-    uint32_t rank[2];
+    uint32_t rank[2], excl[2];
     int64_t qrow[2];
     uint64_t* cbuf[2];
 #pragma unroll
@@ -161,6 +161,10 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         rref[nb] = (COUNT && valid) ? p.rank_ref[qrow[nb]] : INFINITY;
         cnt[nb] = 0;
         rank[nb] = 0;
+        {
+            const int64_t e = qrow[nb] + p.rank_excl;          // the query's own (positive) column, if any
+            excl[nb] = (COUNT && e >= 0 && e < p.nc) ? (uint32_t)e : 0xFFFFFFFFu;
+        }
         cbuf[nb] = p.cand + ((int64_t)ss * p.nq_pad + (qrow[nb] < p.nq_pad ? qrow[nb] : 0)) * CAND_CAP;
     }
 
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                            rank[nb] += (v[r] > rref[nb] && (!partial || ci < (uint32_t)p.nc)) ? 1u : 0u;
+                            rank[nb] += (v[r] > rref[nb] && ci != excl[nb] && (!partial || ci < (uint32_t)p.nc)) ? 1u : 0u;
                         }
                     }
                     // quick reject: nothing in this 32x32 block beats any threshold
@@ -432,7 +436,8 @@ static hipError_t launch_sweep(const SweepParams& p, int grid, hipStream_t st) {
 
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
               int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
-              const float* rank_ref, int64_t* out_rank, void* workspace, hipStream_t st, hipError_t* herr) {
+              const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
+              hipError_t* herr) {
     SweepPlan pl;
     sweep_plan(nq, nc, &pl);
     const int rowbytes = d * elem_bytes(dt);
@@ -459,6 +464,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         p.q_scale = q_scale ? q_scale + q0 : nullptr;
         p.c_scale = c_scale;
         p.rank_ref = count ? rank_ref + q0 : nullptr;
+        p.rank_excl = (rank_self_offset == INT64_MIN) ? INT64_MIN / 2 : rank_self_offset + q0;
         p.cand = cand;
         p.rank_part = rank_part;
         const int grid = p.n_qblocks * p.n_splits;

@@ -39,7 +39,7 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
 
 
 def topk(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.Tensor] = None,
-         idx_offset: int = 0, rank_ref: Optional[torch.Tensor] = None,
+         idx_offset: int = 0, rank_ref: Optional[torch.Tensor] = None, rank_self_offset: Optional[int] = None,
          q_scale: Optional[torch.Tensor] = None, c_scale: Optional[torch.Tensor] = None
          ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
     """Exact per-row top-k of q @ c.T on the matrix cores; returns (values f32 [nq,k], indices i64
@@ -69,17 +69,18 @@ def topk(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.T
         _lib.check(-1, "abc_topk_workspace_bytes")
     ws = workspace(need, q.device)
     st = _stream(q)
+    self_off = _lib.NO_SELF if rank_self_offset is None else int(rank_self_offset)
     if dt == _lib.DT_I8:
         if q_scale is None or c_scale is None:
             raise _lib.AbcError("int8 search needs q_scale and c_scale")
         q_scale, c_scale = q_scale.to(torch.float32).contiguous(), c_scale.to(torch.float32).contiguous()
         rc = lib.abc_topk_i8(q.data_ptr(), q_scale.data_ptr(), nq, c.data_ptr(), c_scale.data_ptr(), nc, d, k,
                              _ptr(upper_bound), idx_offset, out_val.data_ptr(), out_idx.data_ptr(),
-                             _ptr(rank_ref), _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
+                             _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
     else:
         fn = lib.abc_topk_bf16 if dt == _lib.DT_BF16 else lib.abc_topk_f32
         rc = fn(q.data_ptr(), nq, c.data_ptr(), nc, d, k, _ptr(upper_bound), idx_offset, out_val.data_ptr(),
-                out_idx.data_ptr(), _ptr(rank_ref), _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
+                out_idx.data_ptr(), _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "abc_topk")
     return out_val, out_idx, out_rank
 

@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference's contrastive loss, same names and argument meaning.
+
+    Temperature               model/modeling_abc.py:36-43
+    compute_contrastive_loss  model/abc_util.py:43-56
+    compute_gathered_loss     model/abc_util.py:5-31
+
+The logits / logsumexp / label-smoothed cross entropy / argmax and their backward run in
+libabcsearch.so (abc_infonce_fwd / abc_infonce_bwd, exact fp32 on the matrix cores); the candidate
+all-gather is torch.distributed (RCCL over xGMI on ROCm).  No CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .kernels import _stream
+
+
+class Temperature(torch.nn.Module):
+    """Scalar learned temperature, init 0.07; forward(x) = x / temp (model/modeling_abc.py:36-43)."""
+
+    def __init__(self, init: float = 0.07):
+        super().__init__()
+        self.temp = torch.nn.Parameter(torch.tensor(init, requires_grad=True, dtype=torch.float32))
+
+    def forward(self, x):
+        return x / (self.temp.float())
+
+
+class _InfoNCE(torch.autograd.Function):
+    """loss, argmax = InfoNCE(q, p, temp); gradient reaches q, the first `local_rows` rows of p, temp."""
+
+    @staticmethod
+    def forward(ctx, q, p, temp, eps: float, local_rows: int):
+        if not (q.is_cuda and p.is_cuda):
+            raise _lib.AbcError("InfoNCE kernels run on the GPU only (no CPU fallback)")
+        lib = _lib.load()
+        q, p = q.float().contiguous(), p.float().contiguous()
+        B, d = q.shape
+        C = p.shape[0]
+        need = lib.abc_infonce_workspace_bytes(B, C, d)
+        if need == 0:
+            raise _lib.AbcError(f"InfoNCE: unsupported shape B={B} C={C} d={d} (need B <= C, d % 8 == 0)")
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)      # also carries the logits to backward
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        lse = torch.empty((B,), dtype=torch.float32, device=q.device)
+        amax = torch.empty((B,), dtype=torch.int32, device=q.device)
+        t = temp.detach().to(device=q.device, dtype=torch.float32).reshape(1).contiguous()   # stays on the device
+        rc = lib.abc_infonce_fwd(q.data_ptr(), p.data_ptr(), t.data_ptr(), float(eps), B, C, d, loss.data_ptr(),
+                                 lse.data_ptr(), amax.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q))
+        _lib.check(rc, "abc_infonce_fwd")
+        ctx.save_for_backward(q, p, lse, ws, t)
+        ctx.meta = (float(eps), B, C, d, int(local_rows), temp.dtype)
+        ctx.mark_non_differentiable(amax)
+        return loss, amax
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_amax):
+        q, p, lse, ws, t = ctx.saved_tensors
+        eps, B, C, d, local_rows, tdtype = ctx.meta
+        lib = _lib.load()
+        need_q, need_p, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        go = grad_loss.detach().float().contiguous()
+        dq = torch.empty_like(q) if need_q else None
+        dp = None
+        if need_p:
+            dp = torch.zeros_like(p) if local_rows < C else torch.empty_like(p)
+        dt = torch.empty((), dtype=torch.float32, device=q.device) if need_t else None
+        rc = lib.abc_infonce_bwd(q.data_ptr(), p.data_ptr(), lse.data_ptr(), t.data_ptr(), eps, go.data_ptr(), B, C, d,
+                                 local_rows if need_p else 0, None if dq is None else dq.data_ptr(),
+                                 None if dp is None else dp.data_ptr(), None if dt is None else dt.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream(q))
+        _lib.check(rc, "abc_infonce_bwd")
+        return dq, dp, (None if dt is None else dt.to(tdtype)), None, None
+
+
+def _temp_param(temperature) -> torch.Tensor:
+    t = getattr(temperature, "temp", temperature)
+    if not torch.is_tensor(t):
+        t = torch.tensor(float(t), dtype=torch.float32)
+    return t
+
+
+def _loss_and_acc(q_embeds, p_embeds, temperature, label_smoothing, local_rows):
+    temp = _temp_param(temperature)
+    loss, amax = _InfoNCE.apply(q_embeds, p_embeds, temp.to(q_embeds.device), float(label_smoothing), local_rows)
+    bs = q_embeds.size(0)
+    targets = torch.arange(bs, device=amax.device, dtype=amax.dtype)
+    accuracy = (amax == targets).sum() / bs
+    return loss, accuracy
+
+
+def compute_contrastive_loss(q_embeds, p_embeds, temperature, label_smoothing=0.0):
+    """score = temperature(q @ p.T); cross entropy against arange(bs) with label smoothing; argmax
+    accuracy.  Same call and return as model/abc_util.py:43-56; differentiable w.r.t. q_embeds,
+    p_embeds and temperature.temp."""
+    return _loss_and_acc(q_embeds, p_embeds, temperature, label_smoothing, p_embeds.size(0))
+
+
+def gathered_candidates(c_emb: torch.Tensor):
+    """all_gather of the candidate block, local block swapped into slot 0 (model/abc_util.py:15-27).
+    Returns (c_global [W*n, D] -- rows [0, n) are the local, grad-carrying block -- and n)."""
+    n = c_emb.size(0)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return c_emb, n
+    world, rank = dist.get_world_size(), dist.get_rank()
+    gathered = torch.empty((world * n,) + tuple(c_emb.shape[1:]), dtype=c_emb.dtype, device=c_emb.device)
+    dist.all_gather_into_tensor(gathered, c_emb.detach().contiguous())      # one collective, no gradient
+    gathered = gathered.view((world,) + tuple(c_emb.shape))
+    order = list(range(world))
+    order[0], order[rank] = order[rank], order[0]
+    blocks = [c_emb if r == rank else gathered[r] for r in order]
+    return torch.cat(blocks, dim=0), n
+
+
+def compute_gathered_loss(q_emb, c_emb, temperature, label_smoothing=0.0):
+    """Compute the loss by gathering candidates across GPUs; the first [batch_size] entries of c_emb
+    are the positives.  Same call and return as model/abc_util.py:5-31: (loss, accuracy, num_cand);
+    queries are not gathered and only the local candidate block receives a gradient."""
+    q_emb = q_emb.float()
+    c_emb = c_emb.float()
+    c_global, n_local = gathered_candidates(c_emb)
+    if c_global is c_emb:
+        loss, acc = _loss_and_acc(q_emb, c_emb, temperature, label_smoothing, n_local)
+    else:
+        # the gathered blocks are constants: only rows [0, n_local) of c_global get a gradient, and the
+        # kernel writes exactly those (torch.cat routes them back to c_emb)
+        loss, acc = _loss_and_acc(q_emb, c_global, temperature, label_smoothing, n_local)
+    num_cand = torch.tensor([c_global.size(0)], device=loss.device)
+    return loss, acc, num_cand

@@ -1,0 +1,95 @@
+"""Corpus row-sharded search over the GPUs of one node (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm).
+
+The reference searches on a single GPU (script/embed_for_neg_mining.sh:16); sharding is the build's
+own multi-GPU form: every rank holds rows [lo, hi) of the corpus, sees every query,
+produces a local top-k with GLOBAL indices, and the per-rank lists are exchanged with ONE all-gather
+and merged on the device (abc_topk_merge).  The 0.95-positive rule needs s_pos[i] = q_i . c_i, which
+only the shard owning row i can compute: owners fill their rows, one all-reduce(SUM) replicates it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of rank `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@dataclass
+class Backend:
+    """The three device operations the sharded driver needs.  The default binds the HIP kernels;
+    CPU-only tests of the exchange logic bind a checker instead (tests/ only)."""
+    topk: Callable          # (q, c_shard, k, upper_bound, idx_offset) -> (vals [nq,k], idx [nq,k] global, -1 = hole)
+    rowdot: Callable        # (q_rows, c_rows) -> [n] f32
+    merge: Callable         # (vals [P,nq,k], idx [P,nq,k]) -> (vals [nq,k], idx [nq,k])
+
+
+def hip_backend() -> Backend:
+    from . import search, kernels
+
+    def _topk(q, c, k, ub, off):
+        v, i, _ = search.topk(q, c, k, upper_bound=ub, idx_offset=off)
+        return v, i
+
+    def _rowdot(q, c):
+        return kernels.rowdot(q.data, c.data, q_scale=q.scale, c_scale=c.scale)
+
+    return Backend(topk=_topk, rowdot=_rowdot, merge=kernels.merge_topk)
+
+
+class ShardedCorpus:
+    """This rank's rows [lo, hi) of an n_total-row corpus."""
+
+    def __init__(self, shard, lo: int, n_total: int, group=None, backend: Optional[Backend] = None):
+        self.shard, self.lo, self.n_total = shard, lo, n_total
+        self.hi = lo + shard.shape[0]
+        self.group = group
+        self.backend = backend or hip_backend()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    # -- exchange steps -------------------------------------------------------------------------
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t.unsqueeze(0)
+        # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [world, ...]
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out.view((self.world,) + tuple(t.shape))
+
+    def positive_scores(self, q, offset: int) -> torch.Tensor:
+        """s_pos[i] = q[i] . corpus[offset + i], replicated on every rank."""
+        n = q.shape[0]
+        dev = q.data.device if hasattr(q, "data") else q.device
+        s = torch.zeros((n,), dtype=torch.float32, device=dev)
+        a, b = max(self.lo, offset), min(self.hi, offset + n)     # global rows owned here
+        if a < b:
+            s[a - offset:b - offset] = self.backend.rowdot(q.rows(a - offset, b - offset),
+                                                           self.shard.rows(a - self.lo, b - self.lo))
+        if self.world > 1:
+            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+        return s
+
+    def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact global top-k of every query, replicated on every rank."""
+        v, i = self.backend.topk(q, self.shard, k, upper_bound, self.lo)
+        if self.world == 1:
+            return v, i
+        # one exchange: (value f32, index i64) lists of every rank, then a device-side P-way merge
+        gv, gi = self._all_gather(v), self._all_gather(i)
+        return self.backend.merge(gv, gi)
+
+    def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0):
+        """Sharded form of pretrain/create_negative_index.py:45-52 for queries whose positives are
+        corpus rows offset .. offset+n-1.  Returns (idx, vals, s_pos)."""
+        s_pos = self.positive_scores(q, offset)
+        v, i = self.topk(q, k, upper_bound=s_pos * ratio)
+        return i, v, s_pos

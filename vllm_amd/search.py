@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's search entry points, same names and argument meaning.
+
+    get_topk_candidates   evaluate/eval_mscoco.py:18-50 (copies in eval_flickr30k.py, eval_vg_instruct.py,
+                          mmeb_classification.py, mmeb_vqa.py)
+    negatives_for_sample  pretrain/create_negative_index.py:45-52
+    batch / compute_topk  visualization/neg_mine.py:21-77
+
+The arithmetic (score contraction, top-k, mask, compare-count) runs in libabcsearch.so through
+`vllm_amd.kernels`; torch only moves tensors.  There is no CPU path: without a GPU these raise.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels
+from ._lib import AbcError
+
+_COMPUTE = {"f32": torch.float32, "bf16": torch.bfloat16, "i8": torch.int8}
+
+
+def _device(device=None) -> torch.device:
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise AbcError("no ROCm device visible: vllm_amd.search has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Embeddings:
+    """A matrix of embeddings resident in HBM in the dtype the kernels contract in."""
+
+    def __init__(self, x: torch.Tensor, compute: str = "f32", device=None):
+        if compute not in _COMPUTE:
+            raise AbcError(f"compute must be one of {sorted(_COMPUTE)}")
+        dev = _device(device if device is not None else (x.device if x.is_cuda else None))
+        self.compute = compute
+        self.scale = None
+        x = x.to(dev)
+        if compute == "i8":
+            if x.dtype == torch.int8:
+                raise AbcError("pass fp32 embeddings; quantisation happens here")
+            self.data, self.scale = kernels.quantize_i8(x.float())
+        elif compute == "bf16":
+            self.data = x if x.dtype == torch.bfloat16 else kernels.cast_bf16(x.float())
+        else:
+            self.data = x.float().contiguous()
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def rows(self, lo: int, hi: int) -> "Embeddings":
+        out = object.__new__(Embeddings)
+        out.compute, out.data = self.compute, self.data[lo:hi]
+        out.scale = None if self.scale is None else self.scale[lo:hi]
+        return out
+
+    def take(self, index: torch.Tensor) -> "Embeddings":
+        out = object.__new__(Embeddings)
+        out.compute, out.data = self.compute, self.data[index].contiguous()
+        out.scale = None if self.scale is None else self.scale[index].contiguous()
+        return out
+
+
+def topk(q: Embeddings, c: Embeddings, k: int, upper_bound=None, idx_offset: int = 0, rank_ref=None,
+         rank_self_offset=None):
+    """Exact top-k of q @ c.T (values, indices[, rank counts]) on the GPU."""
+    if q.compute != c.compute:
+        raise AbcError("query and corpus must use the same compute dtype")
+    return kernels.topk(q.data, c.data, k, upper_bound=upper_bound, idx_offset=idx_offset, rank_ref=rank_ref,
+                        rank_self_offset=rank_self_offset, q_scale=q.scale, c_scale=c.scale)
+
+
+def positive_scores(q: Embeddings, c: Embeddings, offset: int = 0) -> torch.Tensor:
+    """s_pos[i] = q[i] . c[offset + i]  (create_negative_index.py:48, neg_mine.py:32-35)."""
+    n = q.shape[0]
+    cc = c.rows(offset, offset + n)
+    return kernels.rowdot(q.data, cc.data, q_scale=q.scale, c_scale=cc.scale)
+
+
+# ----------------------------------------------------------------------------------------------
+# a1: evaluate/eval_mscoco.py:18-50
+# ----------------------------------------------------------------------------------------------
+def get_topk_candidates(queries: Sequence[Tuple[object, torch.Tensor]],
+                        candidates: Sequence[Tuple[object, torch.Tensor]], k: int = 3,
+                        compute: str = "f32") -> Dict[object, list]:
+    """Return {query_id: [top-k candidate ids, best first]} by dot-product similarity.
+
+    Same contract as the reference: `queries`/`candidates` are lists of (id, Tensor[1, D]); the dict is
+    keyed by query id, so duplicated ids collapse to the last occurrence.  The score matrix is never
+    materialised and nothing but the [Nq, k] index table returns to the host.
+    """
+    return get_topk_candidates_multi(queries, candidates, (k,), compute=compute)[k]
+
+
+def get_topk_candidates_multi(queries, candidates, ks: Iterable[int], compute: str = "f32") -> Dict[int, Dict[object, list]]:
+    """One search at max(ks), prefixes reused for the smaller k (the reference recomputes the whole
+    matmul for every k in [1, 5, 10], eval_mscoco.py:76-77,87-88)."""
+    ks = sorted(set(int(k) for k in ks))
+    query_ids, query_embs = zip(*queries)
+    candidate_ids, candidate_embs = zip(*candidates)
+    dev = _device()
+    q = Embeddings(torch.cat(query_embs, dim=0), compute, dev)
+    c = Embeddings(torch.cat(candidate_embs, dim=0), compute, dev)
+    kmax = ks[-1]
+    _, idx, _ = topk(q, c, kmax)
+    idx = idx.cpu().tolist()
+    out = {}
+    for k in ks:
+        results = {}
+        for i, q_id in enumerate(query_ids):
+            results[q_id] = [candidate_ids[j] for j in idx[i][:k] if j >= 0]
+        out[k] = results
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# a3: pretrain/create_negative_index.py:45-52
+# ----------------------------------------------------------------------------------------------
+def mine_negatives(q: Embeddings, c: Embeddings, k: int = 100, ratio: float = 0.95, offset: int = 0,
+                   fill_masked_tail: bool = True) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Batched hard-negative mining: for query i (positive = corpus row offset+i) drop every candidate
+    scoring above ratio * s_pos[i] and return the best k of the rest.
+
+    Returns (indices i64 [n,k], values f32 [n,k], s_pos f32 [n]) on the GPU.  If fewer than k
+    candidates survive, the reference's argsort puts masked (-inf) columns in the tail in unspecified
+    order; with fill_masked_tail the tail is filled with masked columns (best first), else with -1.
+    """
+    s_pos = positive_scores(q, c, offset)
+    ub = s_pos * ratio                                   # fp32 multiply, as scores[idx]*.95
+    vals, idx, _ = topk(q, c, k, upper_bound=ub)
+    if fill_masked_tail:
+        holes = (idx < 0).any(dim=1).nonzero().flatten()
+        if holes.numel():
+            v2, i2, _ = topk(q.take(holes), c, k)
+            for r, row in enumerate(holes.tolist()):
+                masked = i2[r][(v2[r] > ub[row]) & (i2[r] >= 0)]
+                n_ok = int((idx[row] >= 0).sum())
+                take = min(k - n_ok, masked.numel())
+                idx[row, n_ok:n_ok + take] = masked[:take]
+    return idx, vals, s_pos
+
+
+def negatives_for_sample(idx: int, negative_dict: dict, q: torch.Tensor, c, top: int = 100, compute: str = "f32"):
+    """Same call as the reference: negative_dict[idx] = the `top` best candidates for query row idx
+    among those not scoring above 0.95 * scores[idx].  `c` may be a tensor or a resident Embeddings
+    (building it once outside the loop avoids re-uploading the corpus per query)."""
+    cc = c if isinstance(c, Embeddings) else Embeddings(c, compute)
+    qq = Embeddings(q[idx:idx + 1], compute, cc.data.device)
+    ids, _, _ = mine_negatives(qq, cc, top, offset=idx)
+    negative_dict[idx] = [j for j in ids[0].cpu().tolist() if j >= 0]
+
+
+# ----------------------------------------------------------------------------------------------
+# a5 / a6: visualization/neg_mine.py
+# ----------------------------------------------------------------------------------------------
+def batch(query, cand, idx: int, batch_size: int, top_k: int, compute: str = "f32"):
+    """Same call and return as neg_mine.batch: CPU tensors (score [b,k] f32, topk_idx [b,k] i64,
+    mask_sum_norm [b] f32 = fraction of candidates scoring above the positive, scores_for_answer [b])."""
+    q = query if isinstance(query, Embeddings) else Embeddings(query, compute)
+    c = cand if isinstance(cand, Embeddings) else Embeddings(cand, compute, q.data.device)
+    n = q.shape[0]
+    batch_idx = idx + batch_size if idx + batch_size < n else n
+    qs = q.rows(idx, batch_idx)
+    s_pos = positive_scores(qs, c, idx)
+    score, topk_idx, rank = topk(qs, c, top_k, rank_ref=s_pos, rank_self_offset=idx)
+    mask_sum_norm = rank.to(torch.float32) / c.shape[0]
+    return score.cpu(), topk_idx.cpu(), mask_sum_norm.cpu(), s_pos.cpu()
+
+
+def compute_topk(path: str, top_k: int, compute: str = "f32", batch_size: int = 3_000) -> None:
+    """neg_mine.compute_topk: reads query.pt / cand.pt under `path`, writes top_k.pt (float32
+    [2,Nq,k]: [0]=scores, [1]=indices as float, the reference's layout), relative_scoring.pt,
+    absolute_scoring.pt and, in addition, top_k_idx.pt (int64 indices, exact beyond 2^24 rows)."""
+    query = torch.load(os.path.join(path, "query.pt"), weights_only=True)
+    cand = torch.load(os.path.join(path, "cand.pt"), weights_only=True)
+    q = Embeddings(query, compute)
+    c = Embeddings(cand, compute, q.data.device)
+    scores, idxs, rel, absolute = [], [], [], []
+    i = 0
+    while i < q.shape[0]:
+        s, t, p, a = batch(q, c, i, batch_size, top_k)
+        scores.append(s)
+        idxs.append(t)
+        rel.append(p)
+        absolute.append(a)
+        i += batch_size
+    scores, idxs = torch.cat(scores, 0), torch.cat(idxs, 0)
+    torch.save(torch.stack((scores, idxs.to(torch.float32))), os.path.join(path, "top_k.pt"))
+    torch.save(idxs, os.path.join(path, "top_k_idx.pt"))
+    torch.save(torch.cat(rel, 0), os.path.join(path, "relative_scoring.pt"))
+    torch.save(torch.cat(absolute, 0), os.path.join(path, "absolute_scoring.pt"))
