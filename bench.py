@@ -180,8 +180,8 @@ def cpu_baseline(batch, shard, nc, gpu_out, dev):
     import oracle
     from vllm_amd import search
     r0, q = batch
-    n_rows = min(262144, shard.shape[0])
-    nq_s = 512
+    n_rows = min(524288, shard.shape[0])
+    nq_s = 2048
     qs_dev = q.rows(0, nq_s)
     cs_dev = shard.rows(0, n_rows)
     q_cpu = qs_dev.data.float().cpu()

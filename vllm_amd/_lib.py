@@ -49,6 +49,9 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise AbcError(f"{LIB_PATH} is missing: build it with `make -C vllm_amd/csrc` "
                            "(or __graft_entry__.build()); there is no fallback path")
+        # torch ships its own libamdhip64.so; import it first so that this library binds to the SAME
+        # HIP runtime (two runtimes in one process do not share devices, streams or allocations)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
