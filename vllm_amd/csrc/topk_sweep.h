@@ -12,7 +12,7 @@ struct SweepParams {
     const char* c;          // [nc, rowbytes] corpus
     int64_t nq, nc;
     int rowbytes;           // d * sizeof(elem), multiple of 128
-    int nk;                 // rowbytes / 128 K-steps per tile
+    int nk;                 // rowbytes / 64 phases per tile
     int k;
     int n_qblocks;          // ceil(nq / 256) of this launch
     int n_splits;           // corpus splits; grid = n_qblocks * n_splits
@@ -23,6 +23,10 @@ struct SweepParams {
     const float* c_scale;   // int8 only
     const float* rank_ref;  // COUNT only
     int64_t rank_excl;      // COUNT only: column (query row + rank_excl) is not counted
+    int debug_flags;        // ABC_DEBUG_FLAGS (timing experiments only; 0 in production)
+    int n_lists;            // 2 * n_splits candidate lists per query
+    int pub_m;              // ceil(k / n_lists): rank each list publishes
+    float* pub;             // [nq_pad][n_lists] published bounds (start at -inf)
     uint64_t* cand;         // [2*n_splits][nq_pad][CAND_CAP] packed keys
     uint32_t* rank_part;    // [2*n_splits][nq_pad]
 };

@@ -7,17 +7,23 @@
 // appended to that query's candidate list in the workspace; a full list is compacted (wave-wide
 // bitonic sort, keep the best k, raise the threshold).  The score matrix never exists in memory.
 //
-// Staging: both operand tiles of a K-step (256 rows x 128 bytes each) go global -> LDS with
-// buffer_load ... lds (no VGPR round trip), double-buffered, one barrier per K-step.  LDS rows are
-// 128 B; the 16-byte chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE address and on the
-// fragment read so that ds_read_b128 is bank-conflict free (LDS-DMA destinations are lane-linear).
+// Staging: the contraction runs in PHASES of 64 bytes per row (32 bf16).  Both operand tiles of a
+// phase (256 rows x 64 B each) go global -> LDS with buffer_load ... lds (no VGPR round trip) into a
+// ring of 4 slots; the loads of phase p+3 are issued while phase p computes, waits are counted
+// (s_waitcnt vmcnt(N), never 0 in steady state) and there is one raw s_barrier per phase.  The
+// 16-byte chunk index is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read
+// so that ds_read_b128 is bank-conflict free (LDS-DMA destinations are lane-linear).
 #include "common.h"
 #include "topk_sweep.h"
+#include <stdlib.h>
 
 #define TILE 256
-#define ROWB 128
-#define STAGE_BYTES (TILE * ROWB)          // one operand, one K-step: 32 KiB
-#define LDS_BYTES (4 * STAGE_BYTES)        // 2 buffers x 2 operands: 128 KiB
+#define ROWB 64                            // bytes of one row staged per phase (32 bf16 / 64 i8 / 16 f32)
+#define STAGE_BYTES (TILE * ROWB)          // one operand, one phase: 16 KiB
+#define SLOT_BYTES (2 * STAGE_BYTES)       // both operands: 32 KiB
+#define N_SLOTS 4                          // ring of phases in LDS: 128 KiB
+#define LDS_BYTES (N_SLOTS * SLOT_BYTES)
+#define AHEAD 3                            // phases of LDS-DMA kept in flight ahead of the compute
 
 // ------------------------------------------------------------------------------------------------
 template <int DT> struct Acc;
@@ -40,15 +46,15 @@ __device__ __forceinline__ void mma_step(typename Acc<DT>::type& acc, const v4i&
     }
 }
 
-// Issue the LDS-DMA loads of one K-step (both operands) into stage buffer `buf`.
-__device__ __forceinline__ void stage_issue(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rq, char* smem, int buf,
-                                            int wave, const int (&voff)[4], int soff) {
-    char* dst = smem + buf * (2 * STAGE_BYTES) + wave * 4096;
+// Issue the LDS-DMA loads of one phase (both operands, 2 + 2 wave-instructions of 16 rows x 64 B).
+__device__ __forceinline__ void stage_issue(__amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rq, char* smem, int slot,
+                                            int wave, const int (&voff)[2], int soff) {
+    char* dst = smem + slot * SLOT_BYTES + wave * 2048;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, LDS_PTR(dst + i * 1024), 16, voff[i], soff, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(dst + STAGE_BYTES + i * 1024), 16, voff[i], soff, 0, 0);
 }
 
@@ -62,32 +68,47 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// Compaction of one query's candidate list: sort (desc), keep the best k, return the new threshold.
-// Called by the whole wave (uniform).  `buf` is wave-uniform.
-__device__ __forceinline__ void compact_list(uint64_t* buf, int n, int k, int lane, float& new_thr, int& new_cnt,
-                                             bool finalize) {
-    uint64_t key[CAND_CAP / 64];
+// Compaction of one query's candidate list: sort (desc), keep the best k, return the new threshold and
+// the value at rank pub_m-1 (the bound this list publishes).  Called by the whole wave (uniform);
+// `buf` is wave-uniform.  E = keys per lane, chosen by the caller from the list length (n <= 64*E).
+template <int E>
+__device__ __forceinline__ void compact_list_e(uint64_t* buf, int n, int k, int pub_m, int lane, float& new_thr,
+                                               int& new_cnt, float& pub_val, bool finalize) {
+    uint64_t key[E];
 #pragma unroll
-    for (int e = 0; e < CAND_CAP / 64; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int i = e * 64 + lane;
         key[e] = (i < n) ? buf[i] : 0ull;
     }
-    wave_sort_desc<CAND_CAP / 64>(key, lane);
+    wave_sort_desc<E>(key, lane);
     const int keep = n < k ? n : k;
 #pragma unroll
-    for (int e = 0; e < CAND_CAP / 64; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int i = e * 64 + lane;
         if (i < keep) buf[i] = key[e];
         else if (finalize && i < k) buf[i] = 0ull;
     }
+    if (finalize && E == 1 && k > 64 && lane + 64 < k) buf[lane + 64] = 0ull;    // pad the part of [keep,k) beyond this E
     // value at rank k-1 becomes the threshold once the list is full
     uint64_t kth = 0;
 #pragma unroll
-    for (int e = 0; e < CAND_CAP / 64; ++e)
+    for (int e = 0; e < E; ++e)
         if (e == ((k - 1) >> 6)) kth = key[e];
     kth = shfl_u64(kth, (k - 1) & 63);
     new_cnt = keep;
     new_thr = (n >= k) ? key_val(kth) : -INFINITY;
+    // every list of the query publishes its value at rank pub_m-1 (pub_m <= 64); with L lists and
+    // L*pub_m >= k the minimum over the lists is a lower bound of the query's global k-th best
+    const uint64_t mth = shfl_u64(key[0], (pub_m - 1) & 63);
+    pub_val = (n >= pub_m) ? key_val(mth) : -INFINITY;
+}
+
+__device__ __forceinline__ void compact_list(uint64_t* buf, int n, int k, int pub_m, int lane, float& new_thr,
+                                             int& new_cnt, float& pub_val, bool finalize) {
+    if (n <= 64) compact_list_e<1>(buf, n, k, pub_m, lane, new_thr, new_cnt, pub_val, finalize);
+    else if (n <= 128) compact_list_e<2>(buf, n, k, pub_m, lane, new_thr, new_cnt, pub_val, finalize);
+    else if (n <= 256) compact_list_e<4>(buf, n, k, pub_m, lane, new_thr, new_cnt, pub_val, finalize);
+    else compact_list_e<CAND_CAP / 64>(buf, n, k, pub_m, lane, new_thr, new_cnt, pub_val, finalize);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -125,29 +146,29 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     const int rowbytes = p.rowbytes;
 
     // ---- staging addresses -----------------------------------------------------------------------
-    int voff[4];
+    int voff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
-        const int swz = (i * 4 + (lane >> 4)) & 7;
-        voff[i] = row * rowbytes + (((lane & 7) ^ swz) << 4);
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane >> 2);
+        const int swz = (lane >> 4) & 3;                  // == (row >> 2) & 3
+        voff[i] = row * rowbytes + (((lane & 3) ^ swz) << 4);
     }
     const int64_t q_rows_left = p.nq - qrow0;
     const uint32_t q_bytes = (uint32_t)((q_rows_left < TILE ? q_rows_left : TILE) * rowbytes);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + qrow0 * rowbytes, q_bytes);
 
-    // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>1)&7)
-    const int swz_r = (l31 >> 1) & 7;
-    int xs[4];
+    // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>2)&3)
+    const int swz_r = (l31 >> 2) & 3;
+    int xs[2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) xs[s] = l31 * ROWB + (((2 * s + h) ^ swz_r) << 4);
+    for (int s = 0; s < 2; ++s) xs[s] = l31 * ROWB + (((2 * s + h) ^ swz_r) << 4);
     const int a_base = wm * 128 * ROWB;                   // corpus operand, rows wm*128 + mb*32 + l31
     const int b_base = STAGE_BYTES + wn * 64 * ROWB;      // query operand, rows wn*64 + nb*32 + l31
 
     // ---- per-query running state (lanes l and l+32 hold the same query and the same values) --------
     const int ss = split * 2 + wm;                        // candidate-list set of this wave
-    float thr[2], ub[2], qsc[2], rref[2];
-    int cnt[2];
+    float thr[2], thr_sh[2], theff[2], ub[2], qsc[2], rref[2];   // local k-th best, shared bound (pred), max of both
+    int cnt[2], base[2];                                 // entries in the list / entries right after its last compaction
     uint32_t rank[2], excl[2];
     int64_t qrow[2];
     uint64_t* cbuf[2];
@@ -156,10 +177,13 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         qrow[nb] = qrow0 + wn * 64 + nb * 32 + l31;
         const bool valid = qrow[nb] < p.nq;
         thr[nb] = valid ? -INFINITY : INFINITY;           // invalid query rows never pass
+        thr_sh[nb] = -INFINITY;
+        theff[nb] = thr[nb];
         ub[nb] = (valid && p.ub) ? p.ub[qrow[nb]] : INFINITY;
         qsc[nb] = (DT == ABC_DT_I8 && valid) ? p.q_scale[qrow[nb]] : 1.0f;
         rref[nb] = (COUNT && valid) ? p.rank_ref[qrow[nb]] : INFINITY;
         cnt[nb] = 0;
+        base[nb] = 0;
         rank[nb] = 0;
         {
             const int64_t e = qrow[nb] + p.rank_excl;          // the query's own (positive) column, if any
@@ -178,9 +202,26 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     };
 
     if (t_begin < t_end) {
-        __amdgpu_buffer_rsrc_t rc = corpus_rsrc(t_begin);
-        stage_issue(rc, rq, smem, 0, wave, voff, 0);
-        int cur = 0;
+        const int nph = nk;                                // phases per tile (rowbytes / 64)
+        const int p_total = (t_end - t_begin) * nph;
+        // issue side of the ring runs AHEAD phases in front of the compute side
+        int is_tile = t_begin, is_k = 0, is_cnt = 0;
+        __amdgpu_buffer_rsrc_t rc_is = corpus_rsrc(t_begin);
+        auto issue_next = [&]() {
+            if (is_tile < t_end) {
+                stage_issue(rc_is, rq, smem, is_cnt & (N_SLOTS - 1), wave, voff, is_k * ROWB);
+                ++is_cnt;
+                if (++is_k == nph) {
+                    is_k = 0;
+                    ++is_tile;
+                    if (is_tile < t_end) rc_is = corpus_rsrc(is_tile);
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) issue_next();
+
+        int ph = 0;
         for (int tile = t_begin; tile < t_end; ++tile) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
@@ -189,33 +230,42 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0;
 
-            __amdgpu_buffer_rsrc_t rc_next = rc;
-            if (tile + 1 < t_end) rc_next = corpus_rsrc(tile + 1);
+            for (int kk = 0; kk < nph; ++kk, ++ph) {
+                // phase ph has landed once at most the loads of the phases behind it are outstanding
+                // (4 LDS-DMA per phase and wave; epilogue stores only make the count conservative)
+                if (ph + 2 < p_total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ph + 1 < p_total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                // every wave has finished reading slot (ph-1)&3: refill it with phase ph+3
+                issue_next();
 
-            for (int ks = 0; ks < nk; ++ks) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (ks + 1 < nk) stage_issue(rc, rq, smem, cur ^ 1, wave, voff, (ks + 1) * ROWB);
-                else if (tile + 1 < t_end) stage_issue(rc_next, rq, smem, cur ^ 1, wave, voff, 0);
-
-                const char* sb = smem + cur * (2 * STAGE_BYTES);
+                const char* sb = smem + (ph & (N_SLOTS - 1)) * SLOT_BYTES;
+                // all 12 fragment reads of the phase are issued up front (48 VGPRs); the MFMAs of the first
+                // 16-deep half start as soon as its 6 fragments are back while the second half is in flight
+                v4i a[2][4], b[2][2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    v4i a[4], b[2];
+                for (int s = 0; s < 2; ++s) {
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) a[mb] = *(const v4i*)(sb + a_base + mb * 32 * ROWB + xs[s]);
+                    for (int nb = 0; nb < 2; ++nb) b[s][nb] = *(const v4i*)(sb + b_base + nb * 32 * ROWB + xs[s]);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) b[nb] = *(const v4i*)(sb + b_base + nb * 32 * ROWB + xs[s]);
+                    for (int mb = 0; mb < 4; ++mb) a[s][mb] = *(const v4i*)(sb + a_base + mb * 32 * ROWB + xs[s]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) mma_step<DT>(acc[mb][nb], a[mb], b[nb]);
+                        for (int nb = 0; nb < 2; ++nb) mma_step<DT>(acc[mb][nb], a[s][mb], b[s][nb]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                cur ^= 1;
+                __builtin_amdgcn_s_setprio(0);
             }
-            rc = rc_next;
 
             // ---- epilogue: filter the 128x64 accumulator block of this wave against the thresholds ----
+            if (p.debug_flags & 1) continue;               // ABC_DEBUG_FLAGS=1: contraction only (timing experiments)
             const int64_t crow_tile = (int64_t)tile * TILE + wm * 128;
             const bool partial = crow_tile + 128 > p.nc;
 #pragma unroll
@@ -248,15 +298,18 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     float m = v[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
-                    if (__ballot(m > thr[nb]) == 0ull) continue;
+                    if (__ballot(m > theff[nb]) == 0ull) continue;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                        bool pass = (v[r] > thr[nb]) && !(v[r] > ub[nb]);
+                        bool pass = (v[r] > theff[nb]) && !(v[r] > ub[nb]);
                         if (partial) pass = pass && (ci < (uint32_t)p.nc);
-                        if (__ballot(pass) != 0ull) {
+                        const uint64_t bal = __ballot(pass);
+                        if (bal != 0ull) {
+                            // lanes l and l+32 append to the same list: lower half first
+                            const uint32_t sel = h ? (uint32_t)bal : (uint32_t)(bal >> 32);
                             const int mine = pass ? 1 : 0;
-                            const int other = __shfl_xor(mine, 32, 64);
+                            const int other = (int)((sel >> l31) & 1u);
                             const int pos = cnt[nb] + (h ? other : 0);
                             if (pass) cbuf[nb][pos] = make_key(v[r], ci);
                             cnt[nb] += mine + other;
@@ -264,10 +317,15 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     }
                 }
             }
-            // ---- once per tile: compact every list that could overflow during the next tile ------------
-            // (a wave appends at most 128 entries per query and tile; CAND_TRIG = CAND_CAP - 128)
+            // ---- once per tile: compact every list that could overflow during the next tile (a wave
+            // appends at most 128 entries per query and tile; CAND_TRIG = CAND_CAP - 128) and, at a refresh
+            // point, every list that has grown since its last compaction, so that it publishes a fresh bound
+            const int ti = tile - t_begin + 1;
+            const bool refresh = p.n_lists > 1 && ti >= 4 && ((ti & (ti - 1)) == 0 || (ti & 31) == 0);
             {
-                uint64_t need = (__ballot(cnt[0] > CAND_TRIG) & 0xFFFFFFFFull) | (__ballot(cnt[1] > CAND_TRIG) << 32);
+                const bool n0 = cnt[0] > CAND_TRIG || (refresh && cnt[0] > base[0]);
+                const bool n1 = cnt[1] > CAND_TRIG || (refresh && cnt[1] > base[1]);
+                uint64_t need = (__ballot(n0) & 0xFFFFFFFFull) | (__ballot(n1) << 32);
                 if (need) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     while (need) {
@@ -276,15 +334,38 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                         const int nbq = jb >> 5, j = jb & 31;
                         const int n = __shfl(nbq ? cnt[1] : cnt[0], j, 64);
                         uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + (qrow0 + wn * 64 + nbq * 32 + j)) * CAND_CAP;
-                        float nt; int nc2;
-                        compact_list(bj, n, p.k, lane, nt, nc2, false);
+                        float nt, pv; int nc2;
+                        compact_list(bj, n, p.k, p.pub_m, lane, nt, nc2, pv, false);
+                        if (lane == 0)
+                            __hip_atomic_store(p.pub + (qrow0 + wn * 64 + nbq * 32 + j) * p.n_lists + ss, pv,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (l31 == j) {
-                            if (nbq) { thr[1] = nt; cnt[1] = nc2; } else { thr[0] = nt; cnt[0] = nc2; }
+                            if (nbq) { thr[1] = nt; cnt[1] = nc2; base[1] = nc2; } else { thr[0] = nt; cnt[0] = nc2; base[0] = nc2; }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 }
             }
+            // ---- now and then: refresh the shared lower bound of each query's global k-th best from what
+            // the other lists (other waves, other workgroups) have published.  Stale values are valid.
+            {
+                if (refresh) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const float* pp = p.pub + (qrow[nb] < p.nq ? qrow[nb] : 0) * p.n_lists;
+                        float mn = INFINITY;
+                        for (int j = 0; j < p.n_lists; ++j)
+                            mn = fminf(mn, __hip_atomic_load(pp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        // v >= mn  <=>  v > pred(mn): keep ties with the bound (the merge settles them by index)
+                        uint32_t u = __float_as_uint(mn);
+                        if (mn == 0.f) u = 0x80000001u;
+                        else if (u != 0xFF800000u && u != 0x7F800000u) u = (u >> 31) ? u + 1 : u - 1;
+                        thr_sh[nb] = (qrow[nb] < p.nq) ? __uint_as_float(u) : INFINITY;
+                    }
+                }
+            }
+            theff[0] = fmaxf(thr[0], thr_sh[0]);
+            theff[1] = fmaxf(thr[1], thr_sh[1]);
         }
     }
 
@@ -297,8 +378,8 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             if (qr >= p.nq) break;                         // uniform
             const int n = __shfl(cnt[nb], j, 64);
             uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + qr) * CAND_CAP;
-            float nt; int nc2;
-            compact_list(bj, n, p.k, lane, nt, nc2, true);
+            float nt, pv; int nc2;
+            compact_list(bj, n, p.k, p.pub_m, lane, nt, nc2, pv, true);
         }
         if constexpr (COUNT) {
             const uint32_t tot = rank[nb] + __shfl_xor(rank[nb], 32, 64);
@@ -418,7 +499,7 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc) {
     SweepPlan pl;
     sweep_plan(nq, nc, &pl);
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
-    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t);
+    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float);
 }
 
 template <int DT, bool COUNT>
@@ -444,6 +525,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
     uint64_t* cand = (uint64_t*)workspace;
     uint32_t* rank_part = (uint32_t*)(cand + lists * CAND_CAP);
+    float* pub = (float*)(rank_part + lists);
     const bool count = rank_ref != nullptr && out_rank != nullptr;
 
     for (int64_t q0 = 0; q0 < nq; q0 += pl.nq_pad) {
@@ -465,6 +547,14 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         p.c_scale = c_scale;
         p.rank_ref = count ? rank_ref + q0 : nullptr;
         p.rank_excl = (rank_self_offset == INT64_MIN) ? INT64_MIN / 2 : rank_self_offset + q0;
+        { const char* e = getenv("ABC_DEBUG_FLAGS"); p.debug_flags = e ? atoi(e) : 0; }
+        p.n_lists = 2 * pl.n_splits;
+        p.pub_m = (k + p.n_lists - 1) / p.n_lists;
+        p.pub = pub;
+        {   // published bounds start at -inf (0xFF800000) for every launch
+            hipError_t em = hipMemsetD32Async((hipDeviceptr_t)pub, 0xFF800000u, lists, st);
+            if (em != hipSuccess) { *herr = em; return ABC_E_HIP; }
+        }
         p.cand = cand;
         p.rank_part = rank_part;
         const int grid = p.n_qblocks * p.n_splits;
