@@ -27,6 +27,7 @@ struct SweepParams {
     int n_lists;            // 2 * n_splits candidate lists per query
     int pub_m;              // ceil(k / n_lists): rank each list publishes
     float* pub;             // [nq_pad][n_lists] published bounds (start at -inf)
+    unsigned long long* dbg; // debug counters
     uint64_t* cand;         // [2*n_splits][nq_pad][CAND_CAP] packed keys
     uint32_t* rank_part;    // [2*n_splits][nq_pad]
 };

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "topk_sweep.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define TILE 256
 #define ROWB 64                            // bytes of one row staged per phase (32 bf16 / 64 i8 / 16 f32)
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     }
 
     acc_t acc[4][2];
+    unsigned dbg_app = 0, dbg_comp = 0, dbg_compn = 0;     // debug counters (ABC_DEBUG_FLAGS & 16)
 
     // ---- software pipeline over (tile, kstep) -----------------------------------------------------
     auto corpus_rsrc = [&](int tile) {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     float m = v[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) m = fmaxf(m, v[r]);
-                    if (__ballot(m > theff[nb]) == 0ull) continue;
+                    if (__ballot(m > theff[nb]) == 0ull || (p.debug_flags & 2)) continue;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
@@ -313,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                             const int pos = cnt[nb] + (h ? other : 0);
                             if (pass) cbuf[nb][pos] = make_key(v[r], ci);
                             cnt[nb] += mine + other;
+                            dbg_app += mine;
                         }
                     }
                 }
@@ -321,12 +324,14 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // appends at most 128 entries per query and tile; CAND_TRIG = CAND_CAP - 128) and, at a refresh
             // point, every list that has grown since its last compaction, so that it publishes a fresh bound
             const int ti = tile - t_begin + 1;
-            const bool refresh = p.n_lists > 1 && ti >= 4 && ((ti & (ti - 1)) == 0 || (ti & 31) == 0);
+            // refresh points: tiles 1,2,3,4,6,8,12,16,24,32,... (two per octave: the bound tightens with log n)
+            const int t3 = ti / 3;
+            const bool refresh = p.n_lists > 1 && ((ti & (ti - 1)) == 0 || (t3 * 3 == ti && (t3 & (t3 - 1)) == 0));
             {
                 const bool n0 = cnt[0] > CAND_TRIG || (refresh && cnt[0] > base[0]);
                 const bool n1 = cnt[1] > CAND_TRIG || (refresh && cnt[1] > base[1]);
                 uint64_t need = (__ballot(n0) & 0xFFFFFFFFull) | (__ballot(n1) << 32);
-                if (need) {
+                if (need && !(p.debug_flags & 4)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     while (need) {
                         const int jb = __builtin_ctzll(need);
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                         const int n = __shfl(nbq ? cnt[1] : cnt[0], j, 64);
                         uint64_t* bj = p.cand + ((int64_t)ss * p.nq_pad + (qrow0 + wn * 64 + nbq * 32 + j)) * CAND_CAP;
                         float nt, pv; int nc2;
+                        dbg_comp += 1; dbg_compn += n;
                         compact_list(bj, n, p.k, p.pub_m, lane, nt, nc2, pv, false);
                         if (lane == 0)
                             __hip_atomic_store(p.pub + (qrow0 + wn * 64 + nbq * 32 + j) * p.n_lists + ss, pv,
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // ---- now and then: refresh the shared lower bound of each query's global k-th best from what
             // the other lists (other waves, other workgroups) have published.  Stale values are valid.
             {
-                if (refresh) {
+                if (refresh && !(p.debug_flags & 8)) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         const float* pp = p.pub + (qrow[nb] < p.nq ? qrow[nb] : 0) * p.n_lists;
@@ -369,6 +375,15 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         }
     }
 
+    if (p.debug_flags & 16) {
+        unsigned a = dbg_app;
+        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)p.dbg + 0, (unsigned long long)a);
+            atomicAdd((unsigned long long*)p.dbg + 1, (unsigned long long)dbg_comp);
+            atomicAdd((unsigned long long*)p.dbg + 2, (unsigned long long)dbg_compn);
+        }
+    }
     // ---- end of the sweep: sort every list, pad to k, publish the rank counts -----------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
@@ -499,7 +514,7 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc) {
     SweepPlan pl;
     sweep_plan(nq, nc, &pl);
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
-    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float);
+    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 64;
 }
 
 template <int DT, bool COUNT>
@@ -526,6 +541,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     uint64_t* cand = (uint64_t*)workspace;
     uint32_t* rank_part = (uint32_t*)(cand + lists * CAND_CAP);
     float* pub = (float*)(rank_part + lists);
+    unsigned long long* dbg = (unsigned long long*)(((uintptr_t)(pub + lists) + 15) & ~(uintptr_t)15);
     const bool count = rank_ref != nullptr && out_rank != nullptr;
 
     for (int64_t q0 = 0; q0 < nq; q0 += pl.nq_pad) {
@@ -555,6 +571,8 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
             hipError_t em = hipMemsetD32Async((hipDeviceptr_t)pub, 0xFF800000u, lists, st);
             if (em != hipSuccess) { *herr = em; return ABC_E_HIP; }
         }
+        p.dbg = dbg;
+        if (p.debug_flags & 16) hipMemsetAsync(dbg, 0, 32, st);
         p.cand = cand;
         p.rank_part = rank_part;
         const int grid = p.n_qblocks * p.n_splits;
@@ -574,6 +592,15 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
                                count ? out_rank + q0 : nullptr);
         e = hipGetLastError();
         if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
+    }
+    {
+        const char* e = getenv("ABC_DEBUG_FLAGS");
+        if (e && (atoi(e) & 16)) {                      // debug only: synchronous read-back of the last launch's counters
+            unsigned long long hc[4] = {0, 0, 0, 0};
+            hipStreamSynchronize(st);
+            hipMemcpy(hc, dbg, 32, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[abc debug] appends=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[1], hc[2]);
+        }
     }
     return ABC_OK;
 }
