@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabcsearch.so")
+LIB_PATH = os.environ.get("ABC_LIB") or os.path.join(_HERE, "libabcsearch.so")   # ABC_LIB: A/B experiments only
 
 DT_BF16, DT_I8, DT_F32 = 0, 1, 2
 MAX_K = 128

@@ -9,8 +9,10 @@
 //
 // Staging: the contraction runs in PHASES of 64 bytes per row (32 bf16).  Both operand tiles of a
 // phase (256 rows x 64 B each) go global -> LDS with buffer_load ... lds (no VGPR round trip) into a
-// ring of 4 slots; the loads of phase p+3 are issued while phase p computes, waits are counted
-// (s_waitcnt vmcnt(N), never 0 in steady state) and there is one raw s_barrier per phase.  The
+// ring of 4 slots; the loads of phase p+3 are issued while phase p is read, waits are counted
+// (s_waitcnt vmcnt(N), never 0 in steady state).  Each phase is a read segment and an MFMA segment
+// separated by raw s_barriers, and the two wave groups that share the SIMDs run one segment apart,
+// so one of them always feeds the matrix pipe while the other reads and issues loads.  The
 // 16-byte chunk index is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read
 // so that ds_read_b128 is bank-conflict free (LDS-DMA destinations are lane-linear).
 #include "common.h"
@@ -24,7 +26,6 @@
 #define SLOT_BYTES (2 * STAGE_BYTES)       // both operands: 32 KiB
 #define N_SLOTS 4                          // ring of phases in LDS: 128 KiB
 #define LDS_BYTES (N_SLOTS * SLOT_BYTES)
-#define AHEAD 3                            // phases of LDS-DMA kept in flight ahead of the compute
 
 // ------------------------------------------------------------------------------------------------
 template <int DT> struct Acc;
@@ -220,8 +221,39 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                 }
             }
         };
+        // wait until phase `phx` has landed: at most the LDS-DMA of the phases issued after it may still be
+        // outstanding (4 per phase and wave; younger epilogue stores only make the count conservative)
+        auto wait_landed = [&](int phx) {
+            const int later = is_cnt - 1 - phx;
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+#define READ_FRAGS(FA, FB, SB, S)                                                                            \
+    {                                                                                                        \
+        _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) FB[nb] = *(const v4i*)((SB) + b_base + nb * 32 * ROWB + xs[S]); \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) FA[mb] = *(const v4i*)((SB) + a_base + mb * 32 * ROWB + xs[S]); \
+    }
+#define MMA_FRAGS(FA, FB)                                                                                    \
+    {                                                                                                        \
+        _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)                                                     \
+            _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) mma_step<DT>(acc[mb][nb], FA[mb], FB[nb]);      \
+    }
+        // Two wave groups (wm = 0 / 1; waves w and w+4 share a SIMD) run the SAME program one barrier
+        // interval apart: while one group is in its read segment R(p) (fragment reads, LDS-DMA issue,
+        // counted wait) its SIMD partners are in their MFMA segment M(p) or M(p-1), so the matrix pipe
+        // of every SIMD always has a wave feeding it.  Hazards (q = any phase):
+        //   - slot q%4 is refilled with phase q+4 in R(q+1): both groups finished R(q) at least one
+        //     barrier earlier;
+        //   - every wave waits for its DMA share of phase q+1 at the end of ITS R(q): that is at
+        //     least one barrier before the first R(q+1) of either group.
 #pragma unroll
-        for (int i = 0; i < AHEAD; ++i) issue_next();
+        for (int i = 0; i < N_SLOTS - 1; ++i) issue_next();
+        wait_landed(0);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one interval behind
+        __builtin_amdgcn_sched_barrier(0);
 
         int ph = 0;
         for (int tile = t_begin; tile < t_end; ++tile) {
@@ -233,41 +265,32 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0;
 
             for (int kk = 0; kk < nph; ++kk, ++ph) {
-                // phase ph has landed once at most the loads of the phases behind it are outstanding
-                // (4 LDS-DMA per phase and wave; epilogue stores only make the count conservative)
-                if (ph + 2 < p_total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if (ph + 1 < p_total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                // every wave has finished reading slot (ph-1)&3: refill it with phase ph+3
-                issue_next();
-
+                // ---- R(ph)
                 const char* sb = smem + (ph & (N_SLOTS - 1)) * SLOT_BYTES;
-                // all 12 fragment reads of the phase are issued up front (48 VGPRs); the MFMAs of the first
-                // 16-deep half start as soon as its 6 fragments are back while the second half is in flight
-                v4i a[2][4], b[2][2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) b[s][nb] = *(const v4i*)(sb + b_base + nb * 32 * ROWB + xs[s]);
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) a[s][mb] = *(const v4i*)(sb + a_base + mb * 32 * ROWB + xs[s]);
-                }
+                v4i a0[4], b0[2], a1[4], b1[2];
+                READ_FRAGS(a0, b0, sb, 0);
+                READ_FRAGS(a1, b1, sb, 1);
+                issue_next();                               // phase ph+3 -> slot (ph-1)%4
+                if (ph + 1 < p_total) wait_landed(ph + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M(ph)
                 __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) mma_step<DT>(acc[mb][nb], a[s][mb], b[s][nb]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                MMA_FRAGS(a0, b0);
+                MMA_FRAGS(a1, b1);
                 __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
 
-            // ---- epilogue: filter the 128x64 accumulator block of this wave against the thresholds ----
-            if (p.debug_flags & 1) continue;               // ABC_DEBUG_FLAGS=1: contraction only (timing experiments)
+            // ---- epilogue segment E: both groups run it in the SAME interval (group 0 skips the interval in
+            // which group 1 finishes its last M), then group 1 skips one to restore the stagger
+            if (wm == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // filter the 128x64 accumulator block of this wave against the thresholds
+            if (!(p.debug_flags & 1)) {                     // ABC_DEBUG_FLAGS=1: contraction only (timing experiments)
             const int64_t crow_tile = (int64_t)tile * TILE + wm * 128;
             const bool partial = crow_tile + 128 > p.nc;
 #pragma unroll
@@ -324,9 +347,16 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // appends at most 128 entries per query and tile; CAND_TRIG = CAND_CAP - 128) and, at a refresh
             // point, every list that has grown since its last compaction, so that it publishes a fresh bound
             const int ti = tile - t_begin + 1;
-            // refresh points: tiles 1,2,3,4,6,8,12,16,24,32,... (two per octave: the bound tightens with log n)
+            // refresh points (the bound tightens with log n): tiles 1,2,3,4,8,16,32,... ; debug modes 1/2
+            // (ABC_DEBUG_FLAGS bits 8-9) try a denser / a sparser schedule
             const int t3 = ti / 3;
-            const bool refresh = p.n_lists > 1 && ((ti & (ti - 1)) == 0 || (t3 * 3 == ti && (t3 & (t3 - 1)) == 0));
+            const bool pow2 = (ti & (ti - 1)) == 0;
+            const int rmode = p.debug_flags >> 8;
+            bool refresh;
+            if (rmode == 0) refresh = pow2 || ti == 3;
+            else if (rmode == 1) refresh = pow2 || (t3 * 3 == ti && (t3 & (t3 - 1)) == 0);
+            else refresh = ti <= 4 || ti == 8 || (pow2 && ((__builtin_ctz(ti) & 1) == 0));
+            refresh = refresh && p.n_lists > 1;
             {
                 const bool n0 = cnt[0] > CAND_TRIG || (refresh && cnt[0] > base[0]);
                 const bool n1 = cnt[1] > CAND_TRIG || (refresh && cnt[1] > base[1]);
@@ -372,7 +402,14 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             }
             theff[0] = fmaxf(thr[0], thr_sh[0]);
             theff[1] = fmaxf(thr[1], thr_sh[1]);
+            }
+            // ---- end of the epilogue segment E
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (wm == 1) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (wm == 0) __builtin_amdgcn_s_barrier();          // balances group 1's extra barrier
     }
 
     if (p.debug_flags & 16) {
