@@ -49,3 +49,56 @@ def test_i8_topk_exact():
     v, i, _ = kernels.topk(qa.to(dev), cb.to(dev), 100, q_scale=sa.to(dev), c_scale=sb.to(dev))
     rv, ri = oracle.topk_ref_i8(qa, sa, cb, sb, 100)
     assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu(), ri)     # bit-exact scores and indices
+
+
+def _adversarial(nq, nc, d, seed=0):
+    """Corpus ordered so that every query's scores ASCEND with the row index: every tile beats the
+    running threshold (the epilogue's worst case)."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.nn.functional.normalize(torch.randn(d, generator=g), dim=0)
+    q = torch.nn.functional.normalize(u[None] + 0.01 * torch.randn(nq, d, generator=g) / d ** 0.5, dim=-1)
+    alpha = torch.linspace(0.05, 0.95, nc)
+    w = torch.randn(nc, d, generator=g)
+    w = torch.nn.functional.normalize(w - (w @ u)[:, None] * u[None], dim=-1)
+    c = alpha[:, None] * u[None] + (1 - alpha ** 2).sqrt()[:, None] * w
+    return q, torch.nn.functional.normalize(c, dim=-1)
+
+
+@pytest.mark.parametrize("k", [64, 128, 7])
+def test_adversarial_ascending_scores(k):
+    q, c = _adversarial(300, 6000, 128)
+    qb, cb = q.to(torch.bfloat16), c.to(torch.bfloat16)
+    v, i, _ = _run(qb, cb, k)
+    oracle.check_topk_parity(qb.float(), cb.float(), v, i, rtol=1e-3)
+    # the true top-k is (nearly) the last k rows
+    assert float((i >= 6000 - 8 * k).float().mean()) > 0.9
+
+
+def test_descending_and_constant_scores():
+    q, c = _adversarial(100, 3000, 64, seed=1)
+    cb = c.flip(0).contiguous().to(torch.bfloat16)               # best rows first: nothing passes after tile 1
+    qb = q.to(torch.bfloat16)
+    v, i, _ = _run(qb, cb, 32)
+    oracle.check_topk_parity(qb.float(), cb.float(), v, i, rtol=1e-3)
+    ones = torch.ones(700, 64, dtype=torch.bfloat16)             # all scores equal: ties -> smallest indices
+    v, i, _ = _run(ones[:5], ones, 10)
+    assert torch.equal(i, torch.arange(10).expand(5, 10)) and bool((v == 64).all())
+
+
+def test_upper_bound_and_rank_through_abi():
+    q, c = oracle.make_clustered(400, 2500, 128, seed=33, n_centres=8)
+    qb, cb = q.to(torch.bfloat16), c.to(torch.bfloat16)
+    s = oracle.scores_f32(qb.float(), cb.float())
+    pos = s[torch.arange(400), torch.arange(400)].clone()
+    from vllm_amd import kernels
+    dev = _dev()
+    v, i, r = kernels.topk(qb.to(dev), cb.to(dev), 64, upper_bound=(pos * 0.95).to(dev), rank_ref=pos.to(dev),
+                           rank_self_offset=0)
+    oracle.check_topk_parity(qb.float(), cb.float(), v.cpu(), i.cpu(), rtol=1e-3, upper_bound=pos * 0.95)
+    s64 = oracle.scores_f32(qb.float(), cb.float(), fp64=True)
+    p64 = pos.double()[:, None]
+    off = torch.ones_like(s64, dtype=torch.bool)
+    off[torch.arange(400), torch.arange(400)] = False
+    lo = ((s64 > p64 + 1e-5 * p64.abs()) & off).sum(1)
+    hi = ((s64 > p64 - 1e-5 * p64.abs()) & off).sum(1)
+    assert bool(((r.cpu() >= lo) & (r.cpu() <= hi)).all())
