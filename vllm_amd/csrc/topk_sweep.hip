@@ -222,8 +222,14 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             }
         };
         // wait until phase `phx` has landed: at most the LDS-DMA of the phases issued after it may still be
-        // outstanding (4 per phase and wave; younger epilogue stores only make the count conservative)
+        // outstanding (4 per phase and wave).  vmcnt counts stores too, in issue order, so an epilogue's
+        // append stores (younger than the loads in flight) would turn the next counted waits into waits
+        // for a store round trip (-10 % measured).  Instead an epilogue drains the ring once before its
+        // first store (the loads have had a whole segment to land) and records the last phase covered:
+        // waits for phases up to `drained_upto` are then no-ops.
+        int drained_upto = -1;
         auto wait_landed = [&](int phx) {
+            if (phx <= drained_upto) return;
             const int later = is_cnt - 1 - phx;
             if (later >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -336,7 +342,11 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                             const int mine = pass ? 1 : 0;
                             const int other = (int)((sel >> l31) & 1u);
                             const int pos = cnt[nb] + (h ? other : 0);
-                            if (pass) cbuf[nb][pos] = make_key(v[r], ci);
+                            if (drained_upto != is_cnt - 1) {      // first store of this epilogue: drain the ring
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                drained_upto = is_cnt - 1;
+                            }
+                            if (pass && !(p.debug_flags & 64)) cbuf[nb][pos] = make_key(v[r], ci);
                             cnt[nb] += mine + other;
                             dbg_app += mine;
                         }
@@ -357,9 +367,10 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             else if (rmode == 1) refresh = pow2 || (t3 * 3 == ti && (t3 & (t3 - 1)) == 0);
             else refresh = ti <= 4 || ti == 8 || (pow2 && ((__builtin_ctz(ti) & 1) == 0));
             refresh = refresh && p.n_lists > 1;
+            const bool refresh_compact = refresh && !(p.debug_flags & 32);
             {
-                const bool n0 = cnt[0] > CAND_TRIG || (refresh && cnt[0] > base[0]);
-                const bool n1 = cnt[1] > CAND_TRIG || (refresh && cnt[1] > base[1]);
+                const bool n0 = cnt[0] > CAND_TRIG || (refresh_compact && cnt[0] > base[0]);
+                const bool n1 = cnt[1] > CAND_TRIG || (refresh_compact && cnt[1] > base[1]);
                 uint64_t need = (__ballot(n0) & 0xFFFFFFFFull) | (__ballot(n1) << 32);
                 if (need && !(p.debug_flags & 4)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    drained_upto = is_cnt - 1;              // the fence drained every load (and store)
                 }
             }
             // ---- now and then: refresh the shared lower bound of each query's global k-th best from what
