@@ -15,8 +15,8 @@
 // so one of them always feeds the matrix pipe while the other reads and issues loads.  The
 // 16-byte chunk index is XOR-swizzled with (row>>2)&3 on the SOURCE address and on the fragment read
 // so that ds_read_b128 is bank-conflict free (LDS-DMA destinations are lane-linear).
-#include "common.h"
-#include "topk_sweep.h"
+#include "../../vllm_amd/csrc/common.h"
+#include "../../vllm_amd/csrc/topk_sweep.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -25,11 +25,7 @@
 #define STAGE_BYTES (TILE * ROWB)          // one operand, one phase: 16 KiB
 #define SLOT_BYTES (2 * STAGE_BYTES)       // both operands: 32 KiB
 #define N_SLOTS 4                          // ring of phases in LDS: 128 KiB
-#define RING_BYTES (N_SLOTS * SLOT_BYTES)
-#define Q_CAP 128                          // per-wave append queue in LDS: Q_CAP keys (8 B) + query slots (1 B)
-#define Q_BYTES (Q_CAP * 9)
-#define LDS_BYTES (RING_BYTES + 8 * Q_BYTES)
-#define LIST_TRIG (CAND_CAP - 128 - Q_CAP) // compact a list that holds more than this at the end of a tile
+#define LDS_BYTES (N_SLOTS * SLOT_BYTES)
 
 // ------------------------------------------------------------------------------------------------
 template <int DT> struct Acc;
@@ -136,15 +132,10 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     {
         const int id = blockIdx.x;
         if ((p.n_qblocks & 7) == 0) {
-            // g XCDs share a group of per*g query blocks and take n_splits/g splits each (g = 1: an XCD sweeps
-            // the whole corpus for 'per' query blocks)
-            const int gsel = (p.debug_flags >> 12) & 3;
-            int g = gsel == 0 ? 4 : gsel == 1 ? 1 : gsel == 2 ? 2 : 8;
-            if (p.n_splits % g) g = 1;
-            const int per = (p.n_qblocks >> 3) * g;
+            const int per = p.n_qblocks >> 3;
             const int x = id & 7, j = id >> 3;
-            qb = (x / g) * per + (j % per);
-            split = (x % g) * (p.n_splits / g) + j / per;
+            qb = x * per + (j % per);
+            split = j / per;
         } else {
             qb = id % p.n_qblocks;
             split = id / p.n_qblocks;
@@ -182,10 +173,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     int cnt[2], base[2];                                 // entries in the list / entries right after its last compaction
     uint32_t rank[2], excl[2];
     int64_t qrow[2];
-    // the 4 best scores this lane has passed on per query (descending): lanes l and l+32 together know 8 real
-    // entries of the list, whose pub_m-th best (pub_m <= 8) is published as the list's bound WITHOUT a compaction
-    float top4[2][4];
-    const bool track = p.pub_m <= 8 && p.n_lists > 1;
+    uint64_t* cbuf[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         qrow[nb] = qrow0 + wn * 64 + nb * 32 + l31;
@@ -199,61 +187,15 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         cnt[nb] = 0;
         base[nb] = 0;
         rank[nb] = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) top4[nb][i] = -INFINITY;
         {
             const int64_t e = qrow[nb] + p.rank_excl;          // the query's own (positive) column, if any
             excl[nb] = (COUNT && e >= 0 && e < p.nc) ? (uint32_t)e : 0xFFFFFFFFu;
         }
+        cbuf[nb] = p.cand + ((int64_t)ss * p.nq_pad + (qrow[nb] < p.nq_pad ? qrow[nb] : 0)) * CAND_CAP;
     }
 
     acc_t acc[4][2];
     unsigned dbg_app = 0, dbg_comp = 0, dbg_compn = 0;     // debug counters (ABC_DEBUG_FLAGS & 16)
-    const bool stamps = (p.debug_flags & 16) != 0;         // ... and cycle stamps of the epilogue's parts
-    uint64_t dbg_t[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;
-    const uint64_t dbg_start = stamps ? __builtin_amdgcn_s_memtime() : 0;
-    const uint64_t dbg_rstart = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-#define STAMP(I)                                                   \
-    if (stamps) {                                                  \
-        const uint64_t now_ = __builtin_amdgcn_s_memtime();        \
-        dbg_t[I] += now_ - dbg_t0;                                 \
-        dbg_t0 = now_;                                             \
-    }
-    // candidate lists of this wave's 64 queries (slot s = nb*32 + l31; qrow0 + 256 <= nq_pad always) and its
-    // append queue in LDS
-    uint64_t* const lists0 = p.cand + ((int64_t)ss * p.nq_pad + qrow0 + wn * 64) * CAND_CAP;
-    uint64_t* const qkey = (uint64_t*)(smem + RING_BYTES + wave * Q_BYTES);
-    uint8_t* const qslt = (uint8_t*)(qkey + Q_CAP);
-    int qn = 0;                                            // entries in the queue (wave-uniform)
-    int drained_upto = -1;                                 // see wait_landed
-    int next_refresh = 1;                                  // tracked mode: next tile (1-based) that refreshes the bounds
-    auto lanes_below = [&](uint64_t m) {                   // number of set bits of m below this lane
-        return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    };
-    // Flush the queue: 64 entries per step, one (scattered) 64-lane store.  Entry e of query slot s goes to
-    // position cnt(s) + (entries of s among the lanes below); lanes l and l+32 own slots l31 and l31+32.
-    auto flush_queue = [&]() {
-        for (int e0 = 0; e0 < qn; e0 += 64) {
-            const int e = e0 + lane;
-            const bool valid = e < qn;
-            const uint64_t key = valid ? qkey[e] : 0ull;
-            const uint32_t sl = valid ? (uint32_t)qslt[e] : 0u;
-            uint64_t same = __ballot(valid), mine5 = same, b5 = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const uint64_t bi = __ballot(valid && ((sl >> i) & 1u));
-                same &= ((sl >> i) & 1u) ? bi : ~bi;
-                if (i < 5) mine5 &= ((l31 >> i) & 1) ? bi : ~bi;
-                else b5 = bi;
-            }
-            const int c0 = __shfl(cnt[0], (int)(sl & 31u), 64), c1 = __shfl(cnt[1], (int)(sl & 31u), 64);
-            const int at = ((sl >> 5) ? c1 : c0) + lanes_below(same);
-            if (valid) lists0[(int64_t)sl * CAND_CAP + at] = key;
-            cnt[0] += __builtin_popcountll(mine5 & ~b5);
-            cnt[1] += __builtin_popcountll(mine5 & b5);
-        }
-        qn = 0;
-    };
 
     // ---- software pipeline over (tile, kstep) -----------------------------------------------------
     auto corpus_rsrc = [&](int tile) {
@@ -285,6 +227,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         // for a store round trip (-10 % measured).  Instead an epilogue drains the ring once before its
         // first store (the loads have had a whole segment to land) and records the last phase covered:
         // waits for phases up to `drained_upto` are then no-ops.
+        int drained_upto = -1;
         auto wait_landed = [&](int phx) {
             if (phx <= drained_upto) return;
             const int later = is_cnt - 1 - phx;
@@ -352,204 +295,20 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // which group 1 finishes its last M), then group 1 skips one to restore the stagger
             if (wm == 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (stamps) dbg_t0 = __builtin_amdgcn_s_memtime();
-            // filter the 128x64 accumulator block of this wave against the thresholds; survivors go to the
-            // wave's append queue in LDS (scattered one-lane global stores from here cost 11 % of the sweep)
-            if (!(p.debug_flags & 1)) {                     // ABC_DEBUG_FLAGS=1: contraction only (timing experiments)
-            const int64_t crow_tile = (int64_t)tile * TILE + wm * 128;
-            const bool partial = crow_tile + 128 > p.nc;
-            const int ti = tile - t_begin + 1;
-            // refresh points.  Tracked mode (pub_m <= 8): publishing a bound costs no compaction, but every
-            // refresh is 2 x n_lists agent-scope (L2-bypassing) loads per lane, so the points are spaced
-            // geometrically: tiles 1..4, then each about 5/4 (ABC_DEBUG_FLAGS bits 8-9: 9/8, 3/2, 2) of the last.
-            // Legacy mode: lists are compacted to publish, at tiles 1,2,3,4,8,16,32,...
-            bool refresh;
-            if (track) {
-                refresh = ti == next_refresh;
-                if (refresh) {
-                    const int rmode = (p.debug_flags >> 8) & 3;
-                    const int step = rmode == 0 ? ti >> 2 : rmode == 1 ? ti >> 3 : rmode == 2 ? ti >> 1 : ti;
-                    next_refresh = ti + (step > 1 ? step : 1);
-                }
-            } else refresh = (ti & (ti - 1)) == 0 || ti == 3;
-            refresh = refresh && p.n_lists > 1;
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                const uint32_t cbase = (uint32_t)(crow_tile + mb * 32 + 4 * h);
-                float csc[16];
-                if constexpr (DT == ABC_DT_I8) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                        csc[r] = (ci < (uint32_t)p.nc) ? p.c_scale[ci] : 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if constexpr (DT == ABC_DT_I8) v[r] = (float)acc[mb][nb][r] * (qsc[nb] * csc[r]);
-                        else v[r] = acc[mb][nb][r];
-                    }
-                    if constexpr (COUNT) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                            rank[nb] += (v[r] > rref[nb] && ci != excl[nb] && (!partial || ci < (uint32_t)p.nc)) ? 1u : 0u;
-                        }
-                    }
-                    // quick reject, two levels: the 32x32 block, then its four groups of 4 rows
-                    float gm[4];
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        gm[g4] = fmaxf(fmaxf(v[4 * g4], v[4 * g4 + 1]), fmaxf(v[4 * g4 + 2], v[4 * g4 + 3]));
-                    const float m = fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3]));
-                    if (__ballot(m > theff[nb]) == 0ull || (p.debug_flags & 2)) continue;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        if (__ballot(gm[g4] > theff[nb]) == 0ull) continue;
-#pragma unroll
-                        for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
-                            const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                            bool pass = (v[r] > theff[nb]) && !(v[r] > ub[nb]);
-                            if (partial) pass = pass && (ci < (uint32_t)p.nc);
-                            const uint64_t bal = __ballot(pass);
-                            if (bal != 0ull) {
-                                {   // keep the lane's 4 best passed scores of this query
-                                    float x = pass ? v[r] : -INFINITY, hi;
-                                    hi = fmaxf(top4[nb][0], x); x = fminf(top4[nb][0], x); top4[nb][0] = hi;
-                                    hi = fmaxf(top4[nb][1], x); x = fminf(top4[nb][1], x); top4[nb][1] = hi;
-                                    hi = fmaxf(top4[nb][2], x); x = fminf(top4[nb][2], x); top4[nb][2] = hi;
-                                    top4[nb][3] = fmaxf(top4[nb][3], x);
-                                }
-                                const int npass = __builtin_popcountll(bal);
-                                if (qn + npass <= Q_CAP) {
-                                    const int pos = qn + lanes_below(bal);
-                                    if (pass) {
-                                        qkey[pos] = make_key(v[r], ci);
-                                        qslt[pos] = (uint8_t)(nb * 32 + l31);
-                                    }
-                                    qn += npass;
-                                } else {
-                                    // queue full (first tiles, adversarial data): append straight to the lists;
-                                    // lanes l and l+32 append to the same list, lower half first
-                                    const uint32_t sel = h ? (uint32_t)bal : (uint32_t)(bal >> 32);
-                                    const int mine = pass ? 1 : 0;
-                                    const int other = (int)((sel >> l31) & 1u);
-                                    const int pos = cnt[nb] + (h ? other : 0);
-                                    if (drained_upto != is_cnt - 1) {  // first store of this epilogue: drain the ring
-                                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                        drained_upto = is_cnt - 1;
-                                    }
-                                    if (pass) lists0[(int64_t)(nb * 32 + l31) * CAND_CAP + pos] = make_key(v[r], ci);
-                                    cnt[nb] += mine + other;
-                                }
-                                dbg_app += pass ? 1 : 0;
-                            }
-                        }
-                    }
-                }
-            }
-            STAMP(0);
-            // ---- once per tile: flush a queue that is more than half full (always at a refresh point)
-            if (qn > Q_CAP / 2 || (refresh && (!track || ti <= 4) && qn > 0)) {
-                if (drained_upto != is_cnt - 1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    drained_upto = is_cnt - 1;
-                }
-                flush_queue();
-            }
-            STAMP(1);
-            // ---- compact every list that could overflow before the next check (until then at most 128 direct
-            // appends and one flush of at most Q_CAP entries; LIST_TRIG = CAND_CAP - 128 - Q_CAP) and, at a refresh
-            // point, every list that has grown since its last compaction, so that it publishes a fresh bound
+            // filter the 128x64 accumulator block of this wave against the thresholds
             {
-                const bool grown = refresh && (!track || ti <= 4);
-                const bool n0 = cnt[0] > LIST_TRIG || (grown && cnt[0] > base[0]);
-                const bool n1 = cnt[1] > LIST_TRIG || (grown && cnt[1] > base[1]);
-                uint64_t need = (__ballot(n0) & 0xFFFFFFFFull) | (__ballot(n1) << 32);
-                if (need) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    while (need) {
-                        const int jb = __builtin_ctzll(need);
-                        need &= need - 1;
-                        const int nbq = jb >> 5, j = jb & 31;
-                        const int n = __shfl(nbq ? cnt[1] : cnt[0], j, 64);
-                        uint64_t* bj = lists0 + (int64_t)jb * CAND_CAP;
-                        float nt, pv; int nc2;
-                        dbg_comp += 1; dbg_compn += n;
-                        compact_list(bj, n, p.k, p.pub_m, lane, nt, nc2, pv, false);
-                        if (lane == 0)
-                            __hip_atomic_store(p.pub + (qrow0 + wn * 64 + jb) * p.n_lists + ss, pv,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (l31 == j) {
-                            if (nbq) { thr[1] = nt; cnt[1] = nc2; base[1] = nc2; } else { thr[0] = nt; cnt[0] = nc2; base[0] = nc2; }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    drained_upto = is_cnt - 1;              // the fence drained every load (and store)
-                    theff[0] = fmaxf(thr[0], thr_sh[0]);
-                    theff[1] = fmaxf(thr[1], thr_sh[1]);
-                }
-            }
-            STAMP(2);
-            // ---- at a refresh point: publish this list's bound (tracked mode; in legacy mode the compaction
-            // above did) and refresh the shared lower bound of each query's global k-th best from what all the
-            // lists (other waves, other workgroups) have published.  Stale values are valid.
-            if (refresh && !(p.debug_flags & 8)) {
+                float m = -INFINITY;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int64_t qr = qrow[nb] < p.nq ? qrow[nb] : 0;
-                    if (track) {
-                        // merge the two lanes' sorted 4 (bitonic: a_i vs b_{3-i}), sort both halves, pick rank pub_m
-                        float o[4], hi4[4], lo4[4];
+                for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(top4[nb][i], 32, 64);
+                    for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            hi4[i] = fmaxf(top4[nb][i], o[3 - i]);
-                            lo4[i] = fminf(top4[nb][i], o[3 - i]);
-                        }
-                        auto sort4_bitonic = [](float (&t)[4]) {        // bitonic input -> descending
-                            float a = fmaxf(t[0], t[2]), c = fminf(t[0], t[2]), b = fmaxf(t[1], t[3]), d = fminf(t[1], t[3]);
-                            t[0] = fmaxf(a, b); t[1] = fminf(a, b); t[2] = fmaxf(c, d); t[3] = fminf(c, d);
-                        };
-                        sort4_bitonic(hi4);
-                        sort4_bitonic(lo4);
-                        float pv = lo4[3];
-                        const int pm = p.pub_m;
-                        pv = pm == 1 ? hi4[0] : pm == 2 ? hi4[1] : pm == 3 ? hi4[2] : pm == 4 ? hi4[3]
-                           : pm == 5 ? lo4[0] : pm == 6 ? lo4[1] : pm == 7 ? lo4[2] : lo4[3];
-                        if (h == 0 && qrow[nb] < p.nq)
-                            __hip_atomic_store(p.pub + qr * p.n_lists + ss, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    const float* pp = p.pub + qr * p.n_lists;
-                    float mn = INFINITY;
-                    for (int j0 = 0; j0 < p.n_lists; j0 += 8) {          // 8 loads in flight
-                        float t8[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            t8[u] = __hip_atomic_load(pp + (j0 + u < p.n_lists ? j0 + u : 0), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) mn = fminf(mn, t8[u]);
-                    }
-                    // v >= mn  <=>  v > pred(mn): keep ties with the bound (the merge settles them by index)
-                    uint32_t u = __float_as_uint(mn);
-                    if (mn == 0.f) u = 0x80000001u;
-                    else if (u != 0xFF800000u && u != 0x7F800000u) u = (u >> 31) ? u + 1 : u - 1;
-                    thr_sh[nb] = (qrow[nb] < p.nq) ? __uint_as_float(u) : INFINITY;
-                }
-            }
-            theff[0] = fmaxf(thr[0], thr_sh[0]);
-            theff[1] = fmaxf(thr[1], thr_sh[1]);
-            STAMP(3);
+                        for (int r = 0; r < 16; ++r) m = fmaxf(m, (float)acc[mb][nb][r]);
+                if (m > 1e30f) cbuf[0][0] = 1;
             }
             // ---- end of the epilogue segment E
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
-            STAMP(4);
             if (wm == 1) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -563,13 +322,9 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             atomicAdd((unsigned long long*)p.dbg + 0, (unsigned long long)a);
             atomicAdd((unsigned long long*)p.dbg + 1, (unsigned long long)dbg_comp);
             atomicAdd((unsigned long long*)p.dbg + 2, (unsigned long long)dbg_compn);
-            for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)p.dbg + 3 + i, (unsigned long long)dbg_t[i]);
-            atomicAdd((unsigned long long*)p.dbg + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_start));
-            atomicAdd((unsigned long long*)p.dbg + 9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_rstart));
         }
     }
     // ---- end of the sweep: sort every list, pad to k, publish the rank counts -----------------------
-    flush_queue();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -699,7 +454,7 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc) {
     SweepPlan pl;
     sweep_plan(nq, nc, &pl);
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
-    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
+    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 64;
 }
 
 template <int DT, bool COUNT>
@@ -757,7 +512,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
             if (em != hipSuccess) { *herr = em; return ABC_E_HIP; }
         }
         p.dbg = dbg;
-        if (p.debug_flags & 16) (void)hipMemsetAsync(dbg, 0, 128, st);
+        if (p.debug_flags & 16) hipMemsetAsync(dbg, 0, 32, st);
         p.cand = cand;
         p.rank_part = rank_part;
         const int grid = p.n_qblocks * p.n_splits;
@@ -781,12 +536,10 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     {
         const char* e = getenv("ABC_DEBUG_FLAGS");
         if (e && (atoi(e) & 16)) {                      // debug only: synchronous read-back of the last launch's counters
-            unsigned long long hc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hc, dbg, sizeof(hc), hipMemcpyDeviceToHost);
+            unsigned long long hc[4] = {0, 0, 0, 0};
+            hipStreamSynchronize(st);
+            hipMemcpy(hc, dbg, 32, hipMemcpyDeviceToHost);
             fprintf(stderr, "[abc debug] appends=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[1], hc[2]);
-            fprintf(stderr, "[abc debug] wave-cycles: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu total=%llu clock=%.3f GHz\n",
-                    hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], 0.1 * (double)hc[8] / (double)(hc[9] ? hc[9] : 1));
         }
     }
     return ABC_OK;

@@ -5,7 +5,7 @@
 #include "../../include/abcsearch.h"
 
 #define CAND_CAP 512   // candidate-list capacity per (list set, query): 4 KiB of 8-byte keys
-#define CAND_TRIG (CAND_CAP - 128)   // compact once a list holds more than this after a tile
+
 
 struct SweepParams {
     const char* q;          // [nq, rowbytes] queries of this launch
