@@ -213,6 +213,19 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     uint64_t dbg_t[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;
     const uint64_t dbg_start = stamps ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t dbg_rstart = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
+#ifdef ABC_PHASE_STAMPS                                            // diagnostic build only: where a phase's cycles go
+    uint64_t ps_t[4] = {0, 0, 0, 0}, ps_t0 = __builtin_amdgcn_s_memtime();
+#define PSTAMP(I)                                                  \
+    {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                         \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();        \
+        ps_t[I] += now_ - ps_t0;                                   \
+        ps_t0 = now_;                                              \
+        __builtin_amdgcn_sched_barrier(0);                         \
+    }
+#else
+#define PSTAMP(I)
+#endif
 #define STAMP(I)                                                   \
     if (stamps) {                                                  \
         const uint64_t now_ = __builtin_amdgcn_s_memtime();        \
@@ -329,25 +342,30 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 
             for (int kk = 0; kk < nph; ++kk, ++ph) {
                 // ---- R(ph)
+                PSTAMP(3);
                 const char* sb = smem + (ph & (N_SLOTS - 1)) * SLOT_BYTES;
                 v4i a0[4], b0[2], a1[4], b1[2];
                 READ_FRAGS(a0, b0, sb, 0);
                 READ_FRAGS(a1, b1, sb, 1);
-                issue_next();                               // phase ph+3 -> slot (ph-1)%4
-                if (ph + 1 < p_total) wait_landed(ph + 1);
+                // ABC_DEBUG_FLAGS=16384 (with 1): no staging at all, the LDS-read + MFMA ceiling of this loop
+                const bool no_dma = (p.debug_flags & 16384) != 0;
+                if (!no_dma) issue_next();                  // phase ph+3 -> slot (ph-1)%4
+                if (ph + 1 < p_total && !no_dma) wait_landed(ph + 1);
+                PSTAMP(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                PSTAMP(1);
                 // ---- M(ph)
                 __builtin_amdgcn_s_setprio(1);
                 MMA_FRAGS(a0, b0);
                 MMA_FRAGS(a1, b1);
                 __builtin_amdgcn_s_setprio(0);
+                PSTAMP(2);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-
             // ---- epilogue segment E: both groups run it in the SAME interval (group 0 skips the interval in
             // which group 1 finishes its last M), then group 1 skips one to restore the stagger
             if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -566,6 +584,9 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)p.dbg + 3 + i, (unsigned long long)dbg_t[i]);
             atomicAdd((unsigned long long*)p.dbg + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_start));
             atomicAdd((unsigned long long*)p.dbg + 9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_rstart));
+#ifdef ABC_PHASE_STAMPS
+            for (int i = 0; i < 4; ++i) atomicAdd((unsigned long long*)p.dbg + 10 + i, (unsigned long long)ps_t[i]);
+#endif
         }
     }
     // ---- end of the sweep: sort every list, pad to k, publish the rank counts -----------------------
@@ -781,12 +802,13 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     {
         const char* e = getenv("ABC_DEBUG_FLAGS");
         if (e && (atoi(e) & 16)) {                      // debug only: synchronous read-back of the last launch's counters
-            unsigned long long hc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long hc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hc, dbg, sizeof(hc), hipMemcpyDeviceToHost);
             fprintf(stderr, "[abc debug] appends=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[1], hc[2]);
             fprintf(stderr, "[abc debug] wave-cycles: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu total=%llu clock=%.3f GHz\n",
                     hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], 0.1 * (double)hc[8] / (double)(hc[9] ? hc[9] : 1));
+            if (hc[10]) fprintf(stderr, "[abc debug] phase stamps: R(read+issue+vmwait)=%llu barrier1=%llu M=%llu barrier2(+E)=%llu\n", hc[10], hc[11], hc[12], hc[13]);
         }
     }
     return ABC_OK;
