@@ -141,7 +141,7 @@ def main():
     flops_per_launch = 2.0 * bq * (hi - lo) * D          # algorithmic: 2*Nc_local*D per query
     achieved = flops_per_launch / (sweep_avg_ms * 1e-3) / 1e12
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    tfile = os.path.join(ROOT, "bench_traffic.json")      # PMC result of the last profiled run (profiles/)
     if os.path.exists(tfile) and world == 1 and nc == NC_FULL:
         try:
             traffic = json.load(open(tfile)).get("sweep_hbm_bytes_per_launch")
