@@ -15,6 +15,7 @@ __all__ = [
     "bf16_round", "scores_f32", "topk_ref", "get_topk_candidates", "recall_i2t", "recall_t2i",
     "negatives_for_sample", "mine_negatives_ref", "neg_mine_batch", "quantize_i8", "scores_i8",
     "topk_ref_i8", "check_topk_parity", "make_clustered", "topk_file_layout",
+    "create_negative_index_ref", "attach_negative_rows", "eval_lines", "karpathy_paths",
 ]
 
 NEG_INF = -math.inf
@@ -313,3 +314,59 @@ def make_clustered(nq: int, nc: int, d: int, seed: int = 1234, n_centres: int = 
     # noise scaled by 1/sqrt(d) so that s_pos = q_i.c_i ~ 1/sqrt(1+q_noise^2) (0.89 at 0.5)
     q = torch.nn.functional.normalize(base + q_noise * torch.randn(nq, d, generator=g) / math.sqrt(d), dim=-1)
     return q.to(dtype), c.to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# a4 / f1: pretrain/create_negative_index.py main(), and the negatives.json consumer
+# --------------------------------------------------------------------------------------
+def create_negative_index_ref(q: torch.Tensor, c: torch.Tensor, top: int = 100) -> str:
+    """Restates create_negative_index.py:33-43: the per-sample loop over all rows and the text that
+    json.dump(negative_dict, f) writes (int keys become strings, default separators)."""
+    import json
+    negative_dict: dict = {}
+    for idx in range(q.shape[0]):
+        negatives_for_sample(idx, negative_dict, q, c.clone(), top=top)
+    return json.dumps(negative_dict)
+
+
+def attach_negative_rows(negative_meta: dict, idx: int, negatives: int) -> list:
+    """Restates dataset_utils/conceptual_captions.py:150-156 up to the row lookup (uses the global
+    np.random state, as the reference does)."""
+    import numpy as np
+    offset = 5
+    starts = np.arange(negatives) * offset
+    offsets = np.random.randint(0, offset, size=negatives)
+    neg_idx = starts + offsets
+    negatives_for_idx = negative_meta[str(idx)]
+    return [negatives_for_idx[i] for i in neg_idx]
+
+
+# --------------------------------------------------------------------------------------
+# f2: evaluate/eval_mscoco.py:56-99 / eval_flickr30k.py:56-100 (everything after the embedding calls)
+# --------------------------------------------------------------------------------------
+def eval_lines(test: List[dict], images: list, text: list) -> List[str]:
+    """The six lines the eval scripts print, computed the reference's way: one get_topk_candidates per
+    direction and k."""
+    lines = []
+    for topk in [1, 5, 10]:
+        cand = get_topk_candidates(images, text, topk)
+        lines.append(f"i2t top{topk} is {recall_i2t(test, cand):.4f}")
+    for topk in [1, 5, 10]:
+        cand = get_topk_candidates(text, images, topk)
+        lines.append(f"t2i top{topk} is {recall_t2i(test, cand):.4f}")
+    return lines
+
+
+def karpathy_paths(json_path: str, image_dir=None) -> List[dict]:
+    """eval_mscoco.py:58-67 / eval_flickr30k.py:58-68: test split with x["image"] filled in."""
+    import json
+    import os
+    with open(json_path, "rb") as f:
+        data = json.loads(f.read())["images"]
+    test = list(filter(lambda x: x["split"] == "test", data))
+    for x in test:
+        if image_dir is None:
+            x["image"] = os.path.join(os.path.dirname(json_path), x["filepath"], x["filename"])
+        else:
+            x["image"] = os.path.join(os.path.dirname(json_path), image_dir, x["filename"])
+    return test
