@@ -135,6 +135,33 @@ int abc_infonce_bwd(const float* q, const float* p, const float* lse, const floa
                     float* dq, float* dp_local, float* d_temp,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * Embedding epilogue: the step that produces the vectors the search and the loss consume.
+ *
+ * Mean pool.  Replaces get_mean_token_embed, model/abc_util.py:33-41:
+ *   out[b,h] = (1/S) sum_s [ids[b,s] != pad_id] * instr[b,s] * hidden[b,s,h]     (divides by S, as torch.mean)
+ *   hidden [B,S,H] bf16 or f32, ids [B,S] i64, instr [B,S] f32 nullable (the instruction mask), out [B,H] f32.
+ *   round_bf16 != 0 (bf16 form only): round the instruction-mask product and the mean to bf16, as the
+ *   reference's bf16 tensors do; 0 keeps the fp32 mean.  H % 8 == 0.
+ */
+int abc_mean_pool_bf16(const void* hidden, const int64_t* ids, int64_t pad_id, const float* instr, int B, int S, int H,
+                       int round_bf16, float* out, void* stream);
+int abc_mean_pool_f32(const void* hidden, const int64_t* ids, int64_t pad_id, const float* instr, int B, int S, int H,
+                      float* out, void* stream);
+
+/*
+ * Projection head + normalisation.  Replaces MLP.forward, model/modeling_abc.py:28-34, and
+ * F.normalize(mlp_head(x).float(), dim=-1), model/modeling_abc.py:151-154 / :178-179 (inference):
+ *   y = x + W2 selu(W1 x + b1) + b2 ;  out = y / max(||y||_2, 1e-12)   (normalize = 0: out = y)
+ *   x [B,H] f32, w1 [Hd,H], b1 [Hd] nullable, w2 [H,Hd], b2 [H] nullable (nn.Linear layouts), fp32 throughout.
+ *   out_f32 [B,H]; optional out_bf16 [B,H] (RNE) and out_i8 [B,H] + out_scale [B] (the abc_quantize_i8 rule),
+ *   i.e. the corpus forms abc_topk_bf16 / abc_topk_i8 contract in.  H % 8 == 0, Hd % 8 == 0.
+ */
+size_t abc_embed_head_workspace_bytes(int B, int H, int Hd);
+int abc_embed_head_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                       int B, int H, int Hd, int normalize, float* out_f32, void* out_bf16, int8_t* out_i8,
+                       float* out_scale, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,26 @@ def gen_neg_mine(neg_mine):
     np.savez_compressed(os.path.join(OUT, "neg_mine_batch.npz"), **out)
 
 
+def gen_mean_pool(abc_util):
+    """abc_util.get_mean_token_embed (model/abc_util.py:33-41) on seeded inputs: fp32 and bf16 hidden states,
+    with and without an instruction mask; padded tails, one all-pad row."""
+    g = torch.Generator().manual_seed(77)
+    B, S, H = 6, 19, 64
+    hidden = torch.randn(B, S, H, generator=g)
+    ids = torch.randint(1, 1000, (B, S), generator=g)
+    lens = [19, 12, 1, 7, 0, 15]
+    for b, n in enumerate(lens):
+        ids[b, n:] = 0
+    instr = (torch.rand(B, S, generator=g) > 0.3).float()
+    out = {"ids": ids.numpy(), "hidden": hidden.numpy(), "instr": instr.numpy(), "pad": np.int64(0)}
+    out["f32_plain"] = abc_util.get_mean_token_embed(ids, hidden, 0).numpy()
+    out["f32_instr"] = abc_util.get_mean_token_embed(ids, hidden, 0, instruction_mask=instr).numpy()
+    hb = hidden.to(torch.bfloat16)
+    out["bf16_plain_bits"] = bf16_bits(abc_util.get_mean_token_embed(ids, hb, 0))
+    out["bf16_instr_bits"] = bf16_bits(abc_util.get_mean_token_embed(ids, hb, 0, instruction_mask=instr.to(torch.bfloat16)))
+    np.savez_compressed(os.path.join(OUT, "mean_pool.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
@@ -171,6 +191,7 @@ def main():
     gen_loss(abc_util)
     gen_neg_mine(neg_mine)
     gen_gathered()
+    gen_mean_pool(abc_util)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 __all__ = ["OracleTemperature", "compute_contrastive_loss", "compute_gathered_loss_from_blocks",
-           "gathered_column_order", "infonce_closed_form"]
+           "gathered_column_order", "infonce_closed_form", "get_mean_token_embed", "OracleMLP", "embed_ref"]
 
 
 class OracleTemperature(torch.nn.Module):
@@ -86,3 +86,43 @@ def infonce_closed_form(q: torch.Tensor, p: torch.Tensor, temp: float, eps: floa
     dp = (g / temp).t() @ q
     dtemp = -(g * s).sum() / (temp * temp)
     return loss, lse, z.argmax(1), dq, dp[:n_local], dtemp
+
+
+# --------------------------------------------------------------------------------------
+# f3: the embedding epilogue that feeds the path
+# --------------------------------------------------------------------------------------
+def get_mean_token_embed(input_ids, hidden_state, padding_token_id, instruction_mask=None):
+    """Restates model/abc_util.py:33-41 verbatim (pinned by tests/golden/mean_pool.npz, which the
+    reference function itself produced)."""
+    if instruction_mask is not None:
+        hidden_state = instruction_mask.unsqueeze(-1) * hidden_state
+    mask = (input_ids != padding_token_id).unsqueeze(-1)
+    masked_states = mask * hidden_state
+    return torch.mean(masked_states, dim=1)
+
+
+class OracleMLP(torch.nn.Module):
+    """Restates model/modeling_abc.py:9-34 (Linear with identity/zero init, SELU, residual).  The module
+    cannot be imported here (timm / flash_attn missing): parity unpinned beyond torch.nn itself."""
+
+    def __init__(self, embed_size, hidden_size=None):
+        super().__init__()
+        hidden_size = hidden_size if hidden_size is not None else embed_size
+        self.linear_layer1 = torch.nn.Linear(embed_size, hidden_size, dtype=torch.float32)
+        self.linear_layer2 = torch.nn.Linear(hidden_size, embed_size, dtype=torch.float32)
+        for lin in (self.linear_layer1, self.linear_layer2):
+            torch.nn.init.eye_(lin.weight)
+            torch.nn.init.zeros_(lin.bias)
+        self.act = torch.nn.SELU()
+
+    def forward(self, x):
+        y = self.linear_layer1(x)
+        y = self.act(y)
+        y = self.linear_layer2(y)
+        return x + y
+
+
+def embed_ref(input_ids, hidden_state, padding_token_id, mlp, instruction_mask=None):
+    """model/modeling_abc.py:172-179 after the backbone: pool -> mlp_head -> .float() -> F.normalize."""
+    pooled = get_mean_token_embed(input_ids, hidden_state, padding_token_id, instruction_mask)
+    return torch.nn.functional.normalize(mlp(pooled.float()).float(), dim=-1)

@@ -206,11 +206,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
-        const uint32_t u = __float_as_uint(x[i]);
-        uint32_t r;
-        if ((u & 0x7FFFFFFFu) > 0x7F800000u) r = (u >> 16) | 0x40u;            // NaN stays NaN
-        else r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                        // round-to-nearest-even
-        o[i] = (uint16_t)r;
+        o[i] = (uint16_t)f32_to_bf16_bits(x[i]);
     }
 }
 extern "C" int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* stream) {

@@ -11,6 +11,13 @@ typedef __attribute__((ext_vector_type(16))) int v16i;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// f32 -> bf16 bits, round-to-nearest-even, NaN stays NaN
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
 // ---- ordered 64-bit keys: larger key == better (larger score; on ties smaller index) ----------
 // key = orderable(score) << 32 | (0xFFFFFFFF - index);  key 0 is reserved for "no entry".
 __device__ __forceinline__ uint32_t f32_orderable(float v) {
