@@ -123,3 +123,37 @@ def test_sharded_mining_exchange_gloo(world):
         idx, vals, sp = ret[r]
         assert torch.allclose(sp, s_pos, atol=1e-6)
         assert torch.equal(idx, ri) and torch.allclose(vals, rv, atol=1e-6)      # replicated and exact on every rank
+
+
+def _gather_grad_worker(rank, world, port, ret):
+    from vllm_amd import loss as L
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    c = torch.randn(3, 5, generator=g, requires_grad=True)
+    w = torch.randn(world * 3, 5, generator=torch.Generator().manual_seed(500 + rank))   # this rank's "loss" weights
+    c_all = L._AllGatherWithGrad.apply(c)
+    (c_all * w).sum().backward()
+    ret[rank] = (c_all.detach(), c.grad.clone(), w)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_differentiable_gather_gloo(world):
+    """Forward: the reference's slot order (own block first, rank 0's block in slot `rank`); backward: the
+    block of rank r receives the sum over ranks s of the weights rank s applied to the slot holding r."""
+    from oracle.loss_oracle import gathered_column_order
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_grad_worker, args=(world, 29750 + world, ret), nprocs=world, join=True)
+    blocks = [torch.randn(3, 5, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    for r in range(world):
+        order = gathered_column_order(r, world)
+        c_all, grad, _ = ret[r]
+        assert torch.equal(c_all, torch.cat([blocks[o] for o in order]))
+        want = torch.zeros(3, 5)
+        for s_rank in range(world):
+            slot = gathered_column_order(s_rank, world).index(r)
+            want += ret[s_rank][2][slot * 3:(slot + 1) * 3]
+        assert torch.allclose(grad, want, atol=1e-6)

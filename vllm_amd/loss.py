@@ -108,18 +108,62 @@ def gathered_candidates(c_emb: torch.Tensor):
     gathered = torch.empty((world * n,) + tuple(c_emb.shape[1:]), dtype=c_emb.dtype, device=c_emb.device)
     dist.all_gather_into_tensor(gathered, c_emb.detach().contiguous())      # one collective, no gradient
     gathered = gathered.view((world,) + tuple(c_emb.shape))
-    order = list(range(world))
-    order[0], order[rank] = order[rank], order[0]
-    blocks = [c_emb if r == rank else gathered[r] for r in order]
+    blocks = [c_emb if r == rank else gathered[r] for r in _slot_order(world, rank)]
     return torch.cat(blocks, dim=0), n
 
 
-def compute_gathered_loss(q_emb, c_emb, temperature, label_smoothing=0.0):
+def _slot_order(world: int, rank: int):
+    """Which rank's block sits in each slot of c_global on `rank`: own block first, rank 0's block in
+    slot `rank` (model/abc_util.py:24-27)."""
+    order = list(range(world))
+    order[0], order[rank] = order[rank], order[0]
+    return order
+
+
+class _AllGatherWithGrad(torch.autograd.Function):
+    """all_gather whose backward is a reduce-scatter(SUM): every rank's loss sends a gradient to every
+    candidate block.  Opt-in; the reference's gather is gradient-free
+    (model/abc_util.py:19-21), UniIR's is this one (torch.distributed.nn.all_gather, clip_sf.py:103)."""
+
+    @staticmethod
+    def forward(ctx, c_emb):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        n = c_emb.size(0)
+        gathered = torch.empty((world * n,) + tuple(c_emb.shape[1:]), dtype=c_emb.dtype, device=c_emb.device)
+        dist.all_gather_into_tensor(gathered, c_emb.detach().contiguous())
+        gathered = gathered.view((world,) + tuple(c_emb.shape))
+        ctx.order = _slot_order(world, rank)
+        ctx.shape = tuple(c_emb.shape)
+        return torch.cat([gathered[r] for r in ctx.order], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        gv = g.contiguous().view((world,) + ctx.shape)
+        canon = torch.empty_like(gv)                       # slot j holds the gradient for rank order[j]'s block
+        for j, r in enumerate(ctx.order):
+            canon[r] = gv[j]
+        if dist.get_backend() == "nccl":                   # RCCL: one reduce-scatter over xGMI
+            out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, canon.view((world * ctx.shape[0],) + ctx.shape[1:]), op=dist.ReduceOp.SUM)
+            return out
+        dist.all_reduce(canon, op=dist.ReduceOp.SUM)        # gloo (CPU tests) has no reduce-scatter
+        return canon[rank].clone()
+
+
+def compute_gathered_loss(q_emb, c_emb, temperature, label_smoothing=0.0, differentiable_gather=False):
     """Compute the loss by gathering candidates across GPUs; the first [batch_size] entries of c_emb
     are the positives.  Same call and return as model/abc_util.py:5-31: (loss, accuracy, num_cand);
-    queries are not gathered and only the local candidate block receives a gradient."""
+    queries are not gathered and only the local candidate block receives a gradient.
+
+    differentiable_gather=True (not in the reference, off by default) lets the gradient of every
+    rank's loss reach every candidate block: backward adds one reduce-scatter of the [W*n, D] gradient."""
     q_emb = q_emb.float()
     c_emb = c_emb.float()
+    if differentiable_gather and dist.is_initialized() and dist.get_world_size() > 1:
+        c_all = _AllGatherWithGrad.apply(c_emb)
+        loss, acc = _loss_and_acc(q_emb, c_all, temperature, label_smoothing, c_all.size(0))
+        return loss, acc, torch.tensor([c_all.size(0)], device=loss.device)
     c_global, n_local = gathered_candidates(c_emb)
     if c_global is c_emb:
         loss, acc = _loss_and_acc(q_emb, c_emb, temperature, label_smoothing, n_local)
