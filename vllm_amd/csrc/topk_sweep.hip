@@ -324,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         //     barrier earlier;
         //   - every wave waits for its DMA share of phase q+1 at the end of ITS R(q): that is at
         //     least one barrier before the first R(q+1) of either group.
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the per-query loads above (see the epilogue's note)
 #pragma unroll
         for (int i = 0; i < N_SLOTS - 1; ++i) issue_next();
         wait_landed(0);
@@ -331,8 +332,15 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one interval behind
         __builtin_amdgcn_sched_barrier(0);
 
+        // ABC_DEBUG_FLAGS=16384 (with 1): no staging at all, the LDS-read + MFMA ceiling of this loop
+        const bool no_dma = (p.debug_flags & 16384) != 0;
         int ph = 0;
         for (int tile = t_begin; tile < t_end; ++tile) {
+            // One real vmcnt(0) per tile, through the builtin that hipcc's waitcnt pass accounts for: without
+            // it the pass guards the fragment registers (shared with the epilogue's load destinations) with a
+            // vmcnt(0) inside the phase loop, i.e. a drain of the ring in EVERY phase.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            drained_upto = is_cnt - 1;
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -340,32 +348,44 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0;
 
-            for (int kk = 0; kk < nph; ++kk, ++ph) {
-                // ---- R(ph)
-                PSTAMP(3);
-                const char* sb = smem + (ph & (N_SLOTS - 1)) * SLOT_BYTES;
-                v4i a0[4], b0[2], a1[4], b1[2];
-                READ_FRAGS(a0, b0, sb, 0);
-                READ_FRAGS(a1, b1, sb, 1);
-                // ABC_DEBUG_FLAGS=16384 (with 1): no staging at all, the LDS-read + MFMA ceiling of this loop
-                const bool no_dma = (p.debug_flags & 16384) != 0;
-                if (!no_dma) issue_next();                  // phase ph+3 -> slot (ph-1)%4
-                if (ph + 1 < p_total && !no_dma) wait_landed(ph + 1);
-                PSTAMP(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                PSTAMP(1);
-                // ---- M(ph)
-                __builtin_amdgcn_s_setprio(1);
-                MMA_FRAGS(a0, b0);
-                MMA_FRAGS(a1, b1);
-                __builtin_amdgcn_s_setprio(0);
-                PSTAMP(2);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // Steady state (the issue side stays inside this tile and exactly 3 phases ahead): straight-line
+            // issue + vmcnt(8).  The last 4 phases of a tile, where the issue side crosses into the next tile
+            // or runs dry, take the general path with its bookkeeping.
+#define PHASE_BODY(FAST)                                                                                     \
+    {                                                                                                        \
+        PSTAMP(3);                                                                                           \
+        const char* sb = smem + (ph & (N_SLOTS - 1)) * SLOT_BYTES;                                           \
+        v4i a0[4], b0[2], a1[4], b1[2];                                                                      \
+        READ_FRAGS(a0, b0, sb, 0);                                                                           \
+        READ_FRAGS(a1, b1, sb, 1);                                                                           \
+        if (!no_dma) {                                                                                       \
+            if (FAST) {                                                                                      \
+                stage_issue(rc_is, rq, smem, (ph + 3) & (N_SLOTS - 1), wave, voff, (kk + 3) * ROWB);         \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                             \
+            } else {                                                                                         \
+                issue_next();                               /* phase ph+3 -> slot (ph-1)%4 */                \
+                if (ph + 1 < p_total) wait_landed(ph + 1);                                                   \
+            }                                                                                                \
+        }                                                                                                    \
+        PSTAMP(0);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        PSTAMP(1);                                                                                           \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        MMA_FRAGS(a0, b0);                                                                                   \
+        MMA_FRAGS(a1, b1);                                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        PSTAMP(2);                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+            int kk = 0;
+            for (; kk < nph - 4; ++kk, ++ph) PHASE_BODY(true);
+            is_cnt += kk;                                   // the fast phases issued one phase each
+            is_k += kk;
+            for (; kk < nph; ++kk, ++ph) PHASE_BODY(false);
             // ---- epilogue segment E: both groups run it in the SAME interval (group 0 skips the interval in
             // which group 1 finishes its last M), then group 1 skips one to restore the stagger
             if (wm == 0) __builtin_amdgcn_s_barrier();
@@ -559,6 +579,11 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     else if (u != 0xFF800000u && u != 0x7F800000u) u = (u >> 31) ? u + 1 : u - 1;
                     thr_sh[nb] = (qrow[nb] < p.nq) ? __uint_as_float(u) : INFINITY;
                 }
+                // every register-destination load of this epilogue has returned; saying so with the builtin
+                // (which hipcc's waitcnt pass accounts for, unlike inline asm) keeps it from guarding the
+                // fragment registers with a vmcnt(0) INSIDE the phase loop, which would drain the ring
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                drained_upto = is_cnt - 1;
             }
             theff[0] = fmaxf(thr[0], thr_sh[0]);
             theff[1] = fmaxf(thr[1], thr_sh[1]);
