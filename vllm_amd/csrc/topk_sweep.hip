@@ -332,8 +332,12 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one interval behind
         __builtin_amdgcn_sched_barrier(0);
 
-        // ABC_DEBUG_FLAGS=16384 (with 1): no staging at all, the LDS-read + MFMA ceiling of this loop
+#ifdef ABC_PHASE_STAMPS
+        // diagnostic build, ABC_DEBUG_FLAGS=16384 (with 1): no staging at all, the LDS-read + MFMA ceiling of this loop
         const bool no_dma = (p.debug_flags & 16384) != 0;
+#else
+        constexpr bool no_dma = false;
+#endif
         int ph = 0;
         for (int tile = t_begin; tile < t_end; ++tile) {
             // One real vmcnt(0) per tile, through the builtin that hipcc's waitcnt pass accounts for: without
