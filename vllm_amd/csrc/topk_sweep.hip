@@ -28,7 +28,8 @@
 #define RING_BYTES (N_SLOTS * SLOT_BYTES)
 #define Q_CAP 128                          // per-wave append queue in LDS: Q_CAP keys (8 B) + query slots (1 B)
 #define Q_BYTES (Q_CAP * 9)
-#define LDS_BYTES (RING_BYTES + 8 * Q_BYTES)
+#define CS_BYTES 512                       // int8: the 128 corpus scales of a wave's tile half
+#define LDS_BYTES (RING_BYTES + 8 * Q_BYTES + 8 * CS_BYTES)
 #define LIST_TRIG (CAND_CAP - 128 - Q_CAP) // compact a list that holds more than this at the end of a tile
 
 // ------------------------------------------------------------------------------------------------
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     uint64_t* const lists0 = p.cand + ((int64_t)ss * p.nq_pad + qrow0 + wn * 64) * CAND_CAP;
     uint64_t* const qkey = (uint64_t*)(smem + RING_BYTES + wave * Q_BYTES);
     uint8_t* const qslt = (uint8_t*)(qkey + Q_CAP);
+    float* const cs_lds = (float*)(smem + RING_BYTES + 8 * Q_BYTES + wave * CS_BYTES);
     int qn = 0;                                            // entries in the queue (wave-uniform)
     int drained_upto = -1;                                 // see wait_landed
     int next_refresh = 1;                                  // tracked mode: next tile (1-based) that refreshes the bounds
@@ -345,6 +347,17 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // vmcnt(0) inside the phase loop, i.e. a drain of the ring in EVERY phase.
             __builtin_amdgcn_s_waitcnt(0x0F70);
             drained_upto = is_cnt - 1;
+            if constexpr (DT == ABC_DT_I8) {
+                // the 128 corpus scales of this wave's half tile ride the LDS-DMA path too (2 pieces of 256 B,
+                // older than every phase load counted below; rows past nc read 0 through the descriptor's range
+                // check).  Loading them in the epilogue cost 15 % of the int8 sweep in exposed latency.
+                const int64_t r0 = (int64_t)tile * TILE + wm * 128;
+                const int64_t left = p.nc - r0;
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc((const char*)(p.c_scale + (left > 0 ? r0 : 0)),
+                                                            (uint32_t)((left <= 0 ? 0 : (left < 128 ? left : 128)) * 4));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR((char*)cs_lds), 4, lane * 4, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR((char*)cs_lds + 256), 4, lane * 4, 256, 0, 0);
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -420,10 +433,12 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                 const uint32_t cbase = (uint32_t)(crow_tile + mb * 32 + 4 * h);
                 float csc[16];
                 if constexpr (DT == ABC_DT_I8) {
+                    // rows mb*32 + 8j + 4h + {0..3}: four consecutive floats of the staged scales per j
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                        csc[r] = (ci < (uint32_t)p.nc) ? p.c_scale[ci] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        const v4f c4 = *(const v4f*)(cs_lds + mb * 32 + 8 * j + 4 * h);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) csc[4 * j + t] = c4[t];
                     }
                 }
 #pragma unroll
