@@ -105,6 +105,9 @@ def _worker(rank, world, port, ret):
     be = parallel.Backend(topk=_topk, rowdot=lambda a, b: (a.data * b.data).sum(-1), merge=_merge)
     sc = parallel.ShardedCorpus(_Emb(c[lo:hi]), lo, c.shape[0], backend=be)
     idx, vals, s_pos = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3)
+    # chunked + overlapped exchange gives the same lists as one exchange
+    v2, i2 = sc.topk(_Emb(q), 16, upper_bound=s_pos * 0.95, chunk=16)
+    assert torch.equal(i2, idx) and torch.equal(v2, vals)
     ret[rank] = (idx, vals, s_pos)
     dist.destroy_process_group()
 

@@ -751,6 +751,10 @@ void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl) {
     pl->n_tiles = (int)((nc + TILE - 1) / TILE);
     const int64_t qblocks_total = (nq + TILE - 1) / TILE;
     pl->qblocks_per_launch = (int)(qblocks_total < 32 ? qblocks_total : 32);
+    {   // timing experiments only: ABC_PLAN_QB = query blocks per launch (splits follow as 256 / that)
+        const char* e = getenv("ABC_PLAN_QB");
+        if (e && atoi(e) >= 8) pl->qblocks_per_launch = (int)(qblocks_total < atoi(e) ? qblocks_total : atoi(e));
+    }
     int s = 256 / pl->qblocks_per_launch;
     if (s < 1) s = 1;
     if (s > 64) s = 64;

@@ -78,14 +78,36 @@ class ShardedCorpus:
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s
 
-    def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Exact global top-k of every query, replicated on every rank."""
-        v, i = self.backend.topk(q, self.shard, k, upper_bound, self.lo)
+    def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None, chunk: int = 8192
+             ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact global top-k of every query, replicated on every rank.  Queries go through the local
+        sweep in chunks; the exchange of chunk i (ONE all-gather of its (value f32, index i64) lists) is
+        enqueued asynchronously and overlaps the sweep of chunk i+1; the P-way merges run at the end."""
+        n = q.shape[0]
         if self.world == 1:
-            return v, i
-        # one exchange: (value f32, index i64) lists of every rank, then a device-side P-way merge
-        gv, gi = self._all_gather(v), self._all_gather(i)
-        return self.backend.merge(gv, gi)
+            return self.backend.topk(q, self.shard, k, upper_bound, self.lo)
+        pending = []
+        for a in range(0, max(n, 1), chunk):
+            b = min(n, a + chunk)
+            qc = q if (a == 0 and b == n) else q.rows(a, b)
+            ub = None if upper_bound is None else upper_bound[a:b]
+            v, i = self.backend.topk(qc, self.shard, k, ub, self.lo)
+            v, i = v.contiguous(), i.contiguous()
+            gv = torch.empty((self.world * v.shape[0], k), dtype=v.dtype, device=v.device)
+            gi = torch.empty((self.world * i.shape[0], k), dtype=i.dtype, device=i.device)
+            wv = dist.all_gather_into_tensor(gv, v, group=self.group, async_op=True)
+            wi = dist.all_gather_into_tensor(gi, i, group=self.group, async_op=True)
+            pending.append((wv, wi, gv, gi, v, i))          # v, i stay alive until the collective has read them
+        outs_v, outs_i = [], []
+        for wv, wi, gv, gi, v, i in pending:
+            wv.wait()
+            wi.wait()
+            mv, mi = self.backend.merge(gv.view(self.world, v.shape[0], k), gi.view(self.world, i.shape[0], k))
+            outs_v.append(mv)
+            outs_i.append(mi)
+        if len(outs_v) == 1:
+            return outs_v[0], outs_i[0]
+        return torch.cat(outs_v, dim=0), torch.cat(outs_i, dim=0)
 
     def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0):
         """Sharded form of pretrain/create_negative_index.py:45-52 for queries whose positives are
