@@ -168,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     const int64_t q_rows_left = p.nq - qrow0;
     const uint32_t q_bytes = (uint32_t)((q_rows_left < TILE ? q_rows_left : TILE) * rowbytes);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + qrow0 * rowbytes, q_bytes);
+    const __amdgpu_buffer_rsrc_t rpub = make_rsrc((const char*)p.pub, (uint32_t)(p.nq_pad * p.n_lists * 4));
 
     // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>2)&3)
     const int swz_r = (l31 >> 2) & 3;
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     acc_t acc[4][2];
     unsigned dbg_app = 0, dbg_comp = 0, dbg_compn = 0;     // debug counters (ABC_DEBUG_FLAGS & 16)
     const bool stamps = (p.debug_flags & 16) != 0;         // ... and cycle stamps of the epilogue's parts
-    uint64_t dbg_t[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;
+    uint64_t dbg_t[6] = {0, 0, 0, 0, 0, 0}, dbg_e[6] = {0, 0, 0, 0, 0, 0}, dbg_t0 = 0;   // all tiles / tiles 1-4 only
+    bool dbg_early = false;
     const uint64_t dbg_start = stamps ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t dbg_rstart = stamps ? __builtin_amdgcn_s_memrealtime() : 0;
 #ifdef ABC_PHASE_STAMPS                                            // diagnostic build only: where a phase's cycles go
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     if (stamps) {                                                  \
         const uint64_t now_ = __builtin_amdgcn_s_memtime();        \
         dbg_t[I] += now_ - dbg_t0;                                 \
+        if (dbg_early) dbg_e[I] += now_ - dbg_t0;                  \
         dbg_t0 = now_;                                             \
     }
     // candidate lists of this wave's 64 queries (slot s = nb*32 + l31; qrow0 + 256 <= nq_pad always) and its
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // which group 1 finishes its last M), then group 1 skips one to restore the stagger
             if (wm == 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (stamps) dbg_t0 = __builtin_amdgcn_s_memtime();
+            if (stamps) { dbg_t0 = __builtin_amdgcn_s_memtime(); dbg_early = tile - t_begin < 4; }
             // filter the 128x64 accumulator block of this wave against the thresholds; survivors go to the
             // wave's append queue in LDS (scattered one-lane global stores from here cost 11 % of the sweep)
             if (!(p.debug_flags & 1)) {                     // ABC_DEBUG_FLAGS=1: contraction only (timing experiments)
@@ -428,6 +431,20 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                 }
             } else refresh = (ti & (ti - 1)) == 0 || ti == 3;
             refresh = refresh && p.n_lists > 1;
+            if (partial) {
+                // the last tile of the corpus: rows past nc (zero-filled by the staging) must never pass or count.
+                // Mask them ONCE here (-inf scores; for int8 a NaN scale below) instead of testing every element.
+                if constexpr (DT != ABC_DT_I8) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool oob = (uint32_t)(crow_tile + mb * 32 + 4 * h) + (r & 3) + 8 * (r >> 2) >= (uint32_t)p.nc;
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb) acc[mb][nb][r] = oob ? -INFINITY : acc[mb][nb][r];
+                        }
+                }
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const uint32_t cbase = (uint32_t)(crow_tile + mb * 32 + 4 * h);
@@ -439,6 +456,11 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                         const v4f c4 = *(const v4f*)(cs_lds + mb * 32 + 8 * j + 4 * h);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) csc[4 * j + t] = c4[t];
+                    }
+                    if (partial) {                           // NaN scale -> NaN score: fails every comparison
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (cbase + (r & 3) + 8 * (r >> 2) >= (uint32_t)p.nc) csc[r] = __builtin_nanf("");
                     }
                 }
 #pragma unroll
@@ -453,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                            rank[nb] += (v[r] > rref[nb] && ci != excl[nb] && (!partial || ci < (uint32_t)p.nc)) ? 1u : 0u;
+                            rank[nb] += (v[r] > rref[nb] && ci != excl[nb]) ? 1u : 0u;
                         }
                     }
                     // quick reject, two levels: the 32x32 block, then its four groups of 4 rows
@@ -469,8 +491,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 #pragma unroll
                         for (int r = 4 * g4; r < 4 * g4 + 4; ++r) {
                             const uint32_t ci = cbase + (r & 3) + 8 * (r >> 2);
-                            bool pass = (v[r] > theff[nb]) && !(v[r] > ub[nb]);
-                            if (partial) pass = pass && (ci < (uint32_t)p.nc);
+                            const bool pass = (v[r] > theff[nb]) && !(v[r] > ub[nb]);
                             const uint64_t bal = __ballot(pass);
                             if (bal != 0ull) {
                                 {   // keep the lane's 4 best passed scores of this query
@@ -510,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             }
             STAMP(0);
             // ---- once per tile: flush a queue that is more than half full (always at a refresh point)
-            if (qn > Q_CAP / 2 || (refresh && (!track || ti <= 4) && qn > 0)) {
+            if (qn > Q_CAP / 2 || (refresh && (!track || ti <= 4) && qn > 0)) {   // (a flush without need is harmless)
                 if (drained_upto != is_cnt - 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     drained_upto = is_cnt - 1;
@@ -522,7 +543,11 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // appends and one flush of at most Q_CAP entries; LIST_TRIG = CAND_CAP - 128 - Q_CAP) and, at a refresh
             // point, every list that has grown since its last compaction, so that it publishes a fresh bound
             {
-                const bool grown = refresh && (!track || ti <= 4);
+                // tracked mode: every grown list is compacted once, after the first tile, to give it a local
+                // threshold for the tiles that run before the first shared bounds arrive (more early compactions
+                // cost more than they filter: -2 % at 200 tiles per split)
+                const int early_last = 1;
+                const bool grown = refresh && (!track || ti <= early_last);
                 const bool n0 = cnt[0] > LIST_TRIG || (grown && cnt[0] > base[0]);
                 const bool n1 = cnt[1] > LIST_TRIG || (grown && cnt[1] > base[1]);
                 uint64_t need = (__ballot(n0) & 0xFFFFFFFFull) | (__ballot(n1) << 32);
@@ -583,14 +608,30 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     }
                     const float* pp = p.pub + qr * p.n_lists;
                     float mn = INFINITY;
-                    for (int j0 = 0; j0 < p.n_lists; j0 += 8) {          // 8 loads in flight
-                        float t8[8];
+                    if ((p.n_lists & 15) == 0) {
+                        // a query's bounds are one or more 64-byte rows: four system-scope (L2-bypassing) 16-byte
+                        // loads per row instead of sixteen 4-byte ones -- every such load is its own memory request
+                        const int vo = (int)(qr * p.n_lists) * 4;
+                        for (int j0 = 0; j0 < p.n_lists; j0 += 16) {
+                            v4i t4[4];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            t8[u] = __hip_atomic_load(pp + (j0 + u < p.n_lists ? j0 + u : 0), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
+                            for (int u = 0; u < 4; ++u)
+                                t4[u] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rpub, vo + (j0 + 4 * u) * 4, 0, 16));
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) mn = fminf(mn, t8[u]);
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) mn = fminf(mn, __int_as_float(t4[u][e]));
+                        }
+                    } else {
+                        for (int j0 = 0; j0 < p.n_lists; j0 += 16) {     // 16 agent-scope loads in flight
+                            float t16[16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u)
+                                t16[u] = __hip_atomic_load(pp + (j0 + u < p.n_lists ? j0 + u : 0), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) mn = fminf(mn, t16[u]);
+                        }
                     }
                     // v >= mn  <=>  v > pred(mn): keep ties with the bound (the merge settles them by index)
                     uint32_t u = __float_as_uint(mn);
@@ -626,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             atomicAdd((unsigned long long*)p.dbg + 1, (unsigned long long)dbg_comp);
             atomicAdd((unsigned long long*)p.dbg + 2, (unsigned long long)dbg_compn);
             for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)p.dbg + 3 + i, (unsigned long long)dbg_t[i]);
+            for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long*)p.dbg + 14 + i, (unsigned long long)dbg_e[i]);
             atomicAdd((unsigned long long*)p.dbg + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_start));
             atomicAdd((unsigned long long*)p.dbg + 9, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dbg_rstart));
 #ifdef ABC_PHASE_STAMPS
@@ -826,7 +868,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
             if (em != hipSuccess) { *herr = em; return ABC_E_HIP; }
         }
         p.dbg = dbg;
-        if (p.debug_flags & 16) (void)hipMemsetAsync(dbg, 0, 128, st);
+        if (p.debug_flags & 16) (void)hipMemsetAsync(dbg, 0, 176, st);
         p.cand = cand;
         p.rank_part = rank_part;
         const int grid = p.n_qblocks * p.n_splits;
@@ -850,12 +892,14 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     {
         const char* e = getenv("ABC_DEBUG_FLAGS");
         if (e && (atoi(e) & 16)) {                      // debug only: synchronous read-back of the last launch's counters
-            unsigned long long hc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned long long hc[21] = {0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hc, dbg, sizeof(hc), hipMemcpyDeviceToHost);
             fprintf(stderr, "[abc debug] appends=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[1], hc[2]);
             fprintf(stderr, "[abc debug] wave-cycles: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu total=%llu clock=%.3f GHz\n",
                     hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], 0.1 * (double)hc[8] / (double)(hc[9] ? hc[9] : 1));
+            fprintf(stderr, "[abc debug] of which tiles 1-4: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu\n",
+                    hc[14], hc[15], hc[16], hc[17], hc[18]);
             if (hc[10]) fprintf(stderr, "[abc debug] phase stamps: R(read+issue+vmwait)=%llu barrier1=%llu M=%llu barrier2(+E)=%llu\n", hc[10], hc[11], hc[12], hc[13]);
         }
     }
