@@ -102,3 +102,34 @@ def test_upper_bound_and_rank_through_abi():
     lo = ((s64 > p64 + 1e-5 * p64.abs()) & off).sum(1)
     hi = ((s64 > p64 - 1e-5 * p64.abs()) & off).sum(1)
     assert bool(((r.cpu() >= lo) & (r.cpu() <= hi)).all())
+
+
+@pytest.mark.parametrize("dtype,nq,nc,d,k", [("bf16", 8192, 60000, 64, 64), ("bf16", 8192, 40000, 128, 128),
+                                             ("i8", 8192, 50000, 128, 100), ("f32", 4096, 30000, 32, 10)])
+def test_long_sweeps_full_launch(dtype, nq, nc, d, k):
+    """A full launch (32 query blocks x 8 splits, 15-30 tiles per split): queue flushes, tracked bounds with
+    geometric refresh, overflow compactions and the list merge, all against the oracle; with and without the
+    0.95-positive upper bound."""
+    from vllm_amd import kernels
+    dev = _dev()
+    q, c = oracle.make_clustered(nq, nc, d, seed=nq + nc + k, n_centres=24)
+    if dtype == "i8":
+        qa, sa = oracle.quantize_i8(q)
+        cb, sb = oracle.quantize_i8(c)
+        s_pos = (qa[:, None, :].int() * cb[:nq][:, None, :].int()).sum(-1).squeeze(1).float() * (sa * sb[:nq])
+        for ub in (None, s_pos * 0.95):
+            v, i, _ = kernels.topk(qa.to(dev), cb.to(dev), k, q_scale=sa.to(dev), c_scale=sb.to(dev),
+                                   upper_bound=None if ub is None else ub.to(dev))
+            rv, ri = oracle.topk_ref_i8(qa, sa, cb, sb, k, upper_bound=ub)
+            assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu(), ri)
+        return
+    if dtype == "bf16":
+        q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+        qd, cd = q.to(torch.bfloat16).to(dev), c.to(torch.bfloat16).to(dev)
+    else:
+        qd, cd = q.to(dev), c.to(dev)
+    s_pos = (q * c[:nq]).sum(-1)
+    for ub in (None, s_pos * 0.95):
+        v, i, _ = kernels.topk(qd, cd, k, upper_bound=None if ub is None else ub.to(dev))
+        torch.cuda.synchronize()
+        oracle.check_topk_parity(q, c, v.cpu(), i.cpu(), rtol=2e-5, upper_bound=ub)
