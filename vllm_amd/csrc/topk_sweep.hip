@@ -792,7 +792,15 @@ static int elem_bytes(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 
 void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl) {
     pl->n_tiles = (int)((nc + TILE - 1) / TILE);
     const int64_t qblocks_total = (nq + TILE - 1) / TILE;
-    pl->qblocks_per_launch = (int)(qblocks_total < 32 ? qblocks_total : 32);
+    // at most 32 query blocks per launch, spread evenly over the launches (98 blocks -> 25+25+24+24, not 32+32+32+2:
+    // a 2-block launch fills 40 of the 256 CUs)
+    {
+        const int64_t launches = (qblocks_total + 31) / 32;
+        int64_t per = launches > 0 ? (qblocks_total + launches - 1) / launches : 1;
+        // multiples of 8 keep the XCD-aware block mapping, which only a long sweep profits from
+        if (per > 8 && pl->n_tiles >= 512) per = (per + 7) & ~(int64_t)7;
+        pl->qblocks_per_launch = (int)(per < 1 ? 1 : per);
+    }
     {   // timing experiments only: ABC_PLAN_QB = query blocks per launch (splits follow as 256 / that)
         const char* e = getenv("ABC_PLAN_QB");
         if (e && atoi(e) >= 8) pl->qblocks_per_launch = (int)(qblocks_total < atoi(e) ? qblocks_total : atoi(e));
