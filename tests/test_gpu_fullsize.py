@@ -82,3 +82,37 @@ def test_upper_bound_rule_at_full_size(data):
         keep = v[r] <= ub[r]
         n = int(keep.sum())
         assert torch.equal(i2[r, :n], i[r][keep]) and torch.equal(v2[r, :n], v[r][keep])
+
+
+def test_int8_config_properties():
+    """BASELINE configs[4] shape (int8, d = 3584, k = 100, per-vector scales) on 4 M rows: sortedness, exact
+    agreement of the returned scores with the int8 rule recomputed from the returned rows, the compare-count
+    checksum, shard + merge == single sweep."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(77)
+    n, d, k, nq = 4_000_000, 3584, 100, 512
+    c8 = torch.empty((n, d), dtype=torch.int8, device=dev)
+    cs = torch.empty((n,), dtype=torch.float32, device=dev)
+    for s in range(0, n, 1 << 18):
+        x = torch.nn.functional.normalize(torch.randn((min(1 << 18, n - s), d), generator=g, device=dev), dim=-1)
+        a, b = kernels.quantize_i8(x)
+        c8[s:s + a.shape[0]], cs[s:s + a.shape[0]] = a, b
+    q8, qs = kernels.quantize_i8(torch.nn.functional.normalize(torch.randn((nq, d), generator=g, device=dev), dim=-1))
+    v, i, _ = kernels.topk(q8, c8, k, q_scale=qs, c_scale=cs)
+    assert bool((v[:, 1:] <= v[:, :-1]).all()) and int(i.min()) >= 0 and int(i.max()) < n
+    assert bool((torch.sort(i, dim=1).values.diff(dim=1) > 0).all())
+    # score_ij = float(sum_k q_ik c_jk) * (q_scale_i * c_scale_j): the integer sum is exact in fp32 products of int8 (< 2^24
+    # per partial?) -- recompute in int64 on the device, then the two fp32 multiplies in the rule's association
+    for a in range(0, nq, 64):
+        rows = c8[i[a:a + 64].reshape(-1)].view(-1, k, d).to(torch.int32)
+        dots = (rows * q8[a:a + 64].to(torch.int32).unsqueeze(1)).sum(-1)
+        ref = dots.to(torch.float32) * (qs[a:a + 64].unsqueeze(1) * cs[i[a:a + 64]])
+        assert torch.equal(ref, v[a:a + 64])
+    kth = v[:, k - 1].contiguous()
+    _, _, rank = kernels.topk(q8, c8, 1, q_scale=qs, c_scale=cs, rank_ref=kth)
+    assert torch.equal(rank, (v > kth[:, None]).sum(dim=1).to(rank.dtype))
+    cut = 1_500_003
+    pv0, pi0, _ = kernels.topk(q8, c8[:cut], k, q_scale=qs, c_scale=cs[:cut])
+    pv1, pi1, _ = kernels.topk(q8, c8[cut:], k, q_scale=qs, c_scale=cs[cut:], idx_offset=cut)
+    mv, mi = kernels.merge_topk(torch.stack([pv0, pv1]), torch.stack([pi0, pi1]))
+    assert torch.equal(mv, v) and torch.equal(mi, i)
