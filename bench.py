@@ -137,9 +137,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    sweep_avg_ms = sum(a.elapsed_time(b) for a, b in sweep_ms) / max(len(sweep_ms), 1)
-    flops_per_launch = 2.0 * bq * (hi - lo) * D          # algorithmic: 2*Nc_local*D per query
-    achieved = flops_per_launch / (sweep_avg_ms * 1e-3) / 1e12
+    # per step: every sweep launch of the step (N > 1 sweeps the step's queries in chunks of 8192)
+    sweep_avg_ms = sum(a.elapsed_time(b) for a, b in sweep_ms) / max(args.steps, 1)
+    flops_per_step = 2.0 * bq * (hi - lo) * D            # algorithmic: 2*Nc_local*D per query
+    achieved = flops_per_step / (sweep_avg_ms * 1e-3) / 1e12
+    launches_per_step = max(len(sweep_ms) // max(args.steps, 1), 1)
+    flops_per_launch = flops_per_step / launches_per_step
     traffic = None
     tfile = os.path.join(ROOT, "bench_traffic.json")      # PMC result of the last profiled run (profiles/)
     if os.path.exists(tfile) and world == 1 and nc == NC_FULL:
@@ -161,7 +164,8 @@ def main():
                    "queries_per_step": bq, "corpus_rows": nc, "d": D, "k": K, "parallelism": f"corpus-shard{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "kernel": "topk_sweep_kernel<bf16>", "avg_launch_ms": sweep_avg_ms,
+                     "kernel": "topk_sweep_kernel<bf16>", "avg_launch_ms": sweep_avg_ms / launches_per_step,
+                     "sweep_ms_per_step": sweep_avg_ms,
                      "flops_per_launch": flops_per_launch},
     }
 
