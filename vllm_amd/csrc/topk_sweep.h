@@ -23,7 +23,13 @@ struct SweepParams {
     const float* c_scale;   // int8 only
     const float* rank_ref;  // COUNT only
     int64_t rank_excl;      // COUNT only: column (query row + rank_excl) is not counted
-    int debug_flags;        // ABC_DEBUG_FLAGS (timing experiments only; 0 in production)
+    int debug_flags;        // ABC_DEBUG_FLAGS (timing experiments only; 0 in production; results are WRONG for 1, 2):
+                            //   1      contraction only, no epilogue       2      quick reject only, nothing appended
+                            //   8      never refresh the shared bounds     16     debug counters + cycle stamps to stderr
+                            //   bits 8-9   refresh spacing 5/4 (0), 9/8, 3/2, 2
+                            //   bits 12-13 XCD groups sharing query blocks: 4 (0), 1, 2, 8
+                            //   16384  (-DABC_PHASE_STAMPS build only) no staging: the LDS-read + MFMA ceiling
+                            // ABC_PLAN_QB=<n> overrides the query blocks per launch; ABC_LIB picks another .so (A/B runs)
     int n_lists;            // 2 * n_splits candidate lists per query
     int pub_m;              // ceil(k / n_lists): rank each list publishes
     float* pub;             // [nq_pad][n_lists] published bounds (start at -inf)
