@@ -1,0 +1,66 @@
+"""Compile-time guard of the sweep kernel's steady-state phase loop (no GPU needed: hipcc cross-compiles).
+
+hipcc's waitcnt pass once guarded the fragment registers with an `s_waitcnt vmcnt(0)` INSIDE that loop -- a
+drain of the LDS-DMA ring in every phase -- after an unrelated register-allocation change.
+The loop must stay: 12 ds_read_b128, 4 LDS-DMA pieces, one counted vmcnt(8), 16 MFMAs, 2 barriers, no
+spill reloads and no scratch traffic."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "vllm_amd", "csrc", "topk_sweep.hip")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    out = tmp_path_factory.mktemp("isa") / "topk_sweep.s"
+    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-value",
+                    "-S", "--cuda-device-only", SRC, "-o", str(out)], check=True, cwd=os.path.dirname(SRC),
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def _kernel(isa_text, dt, count):
+    name = f"_Z17topk_sweep_kernelILi{dt}ELb{count}EEv11SweepParams"
+    m = re.search(rf"^{name}:[^\n]*\n(.*?)s_endpgm", isa_text, re.S | re.M)
+    assert m, name
+    return m.group(1)
+
+
+def _first_inner_loop(body):
+    """The first depth-2 loop of the kernel is the straight-line steady-state phase loop."""
+    lines = body.split("\n")
+    start = next(i for i, l in enumerate(lines) if "This Inner Loop Header" in l)
+    # the loop ends at the first backward conditional branch after its second s_barrier
+    barriers = 0
+    for j in range(start, len(lines)):
+        if re.match(r"\s*s_barrier", lines[j]):
+            barriers += 1
+        if barriers >= 2 and re.match(r"\s*s_cbranch_scc", lines[j]):
+            return lines[start:j + 1]
+    raise AssertionError("loop end not found")
+
+
+@pytest.mark.parametrize("dt,mfma", [(0, "v_mfma_f32_32x32x16_bf16"), (1, "v_mfma_i32_32x32x32_i8"), (2, "v_mfma_f32_32x32x2_f32")])
+def test_steady_state_phase_loop_is_clean(isa, dt, mfma):
+    loop = _first_inner_loop(_kernel(isa, dt, 0))
+    text = "\n".join(loop)
+    assert text.count("ds_read_b128") == 12
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", text)) == 4
+    assert text.count(mfma) == (16 if dt != 2 else 64)
+    assert len(re.findall(r"^\s*s_barrier", text, re.M)) == 2
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
+    assert waits == ["8"], waits                      # the one counted wait; never a drain
+    assert "v_readlane" not in text and "scratch_" not in text and "s_cbranch_vcc" not in text
+
+
+def test_main_variants_do_not_spill_vectors(isa):
+    for dt in (0, 1, 2):
+        body = _kernel(isa, dt, 0)
+        assert "scratch_" not in body, f"dtype {dt}: vector spills in the mining/search variant"

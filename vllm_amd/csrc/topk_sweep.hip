@@ -168,7 +168,6 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
     const int64_t q_rows_left = p.nq - qrow0;
     const uint32_t q_bytes = (uint32_t)((q_rows_left < TILE ? q_rows_left : TILE) * rowbytes);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + qrow0 * rowbytes, q_bytes);
-    const __amdgpu_buffer_rsrc_t rpub = make_rsrc((const char*)p.pub, (uint32_t)(p.nq_pad * p.n_lists * 4));
 
     // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>2)&3)
     const int swz_r = (l31 >> 2) & 3;
@@ -611,6 +610,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                     if ((p.n_lists & 15) == 0) {
                         // a query's bounds are one or more 64-byte rows: four system-scope (L2-bypassing) 16-byte
                         // loads per row instead of sixteen 4-byte ones -- every such load is its own memory request
+                        const __amdgpu_buffer_rsrc_t rpub = make_rsrc((const char*)p.pub, (uint32_t)(p.nq_pad * p.n_lists * 4));
                         const int vo = (int)(qr * p.n_lists) * 4;
                         for (int j0 = 0; j0 < p.n_lists; j0 += 16) {
                             v4i t4[4];
