@@ -444,6 +444,42 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                         }
                 }
             }
+            if constexpr (DT != ABC_DT_I8) {
+                if (track && ti == 1) {
+                    // First tile, empty lists: every score would pass, and giving the lists a threshold used to take a
+                    // sort of all 64 of them.  The wave still holds each query's 128 scores in registers (64 in lane l,
+                    // 64 in lane l+32): a 16-bit radix select on the ordered bit pattern finds a value that at least k
+                    // of them reach, for all 64 queries at once.  It becomes the local threshold BEFORE the filter, so
+                    // this tile appends about k entries per list and nothing is compacted.
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        uint32_t prefix = 0;
+                        for (int bit = 31; bit >= 16; --bit) {
+                            const uint32_t cand = prefix | (1u << bit);
+                            const float fc = orderable_f32(cand);
+                            int c = 0;
+#pragma unroll
+                            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float x = acc[mb][nb][r];
+                                    c += (x >= fc && !(x > ub[nb])) ? 1 : 0;
+                                }
+                            c += __shfl_xor(c, 32, 64);
+                            if (c >= p.k) prefix = cand;
+                        }
+                        if (prefix != 0 && qrow[nb] < p.nq) {
+                            // entries >= value(prefix) must pass `v > thr`: take the float just below it
+                            const float fv = orderable_f32(prefix);
+                            uint32_t u = __float_as_uint(fv);
+                            if (fv == 0.f) u = 0x80000001u;
+                            else if (u != 0xFF800000u && u != 0x7F800000u) u = (u >> 31) ? u + 1 : u - 1;
+                            thr[nb] = __uint_as_float(u);
+                            theff[nb] = fmaxf(thr[nb], thr_sh[nb]);
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 const uint32_t cbase = (uint32_t)(crow_tile + mb * 32 + 4 * h);
@@ -542,10 +578,10 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // appends and one flush of at most Q_CAP entries; LIST_TRIG = CAND_CAP - 128 - Q_CAP) and, at a refresh
             // point, every list that has grown since its last compaction, so that it publishes a fresh bound
             {
-                // tracked mode: every grown list is compacted once, after the first tile, to give it a local
+                // tracked mode, int8: every grown list is compacted once, after the first tile, to give it a local
                 // threshold for the tiles that run before the first shared bounds arrive (more early compactions
                 // cost more than they filter: -2 % at 200 tiles per split)
-                const int early_last = 1;
+                const int early_last = (DT == ABC_DT_I8) ? 1 : 0;      // non-int8: the radix select above did it
                 const bool grown = refresh && (!track || ti <= early_last);
                 const bool n0 = cnt[0] > LIST_TRIG || (grown && cnt[0] > base[0]);
                 const bool n1 = cnt[1] > LIST_TRIG || (grown && cnt[1] > base[1]);
