@@ -133,3 +133,24 @@ def test_long_sweeps_full_launch(dtype, nq, nc, d, k):
         v, i, _ = kernels.topk(qd, cd, k, upper_bound=None if ub is None else ub.to(dev))
         torch.cuda.synchronize()
         oracle.check_topk_parity(q, c, v.cpu(), i.cpu(), rtol=2e-5, upper_bound=ub)
+
+
+def test_several_launches_per_call():
+    """More queries than one launch takes (32 query blocks): per-launch offsets of queries, upper bounds, rank
+    references and outputs; an uneven last launch."""
+    from vllm_amd import kernels
+    dev = _dev()
+    nq, nc, d, k = 2 * 8192 + 300, 3000, 64, 10
+    q, c = oracle.make_clustered(nq, nc, d, seed=4, n_centres=12)
+    q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+    s_ref = (q * c[torch.arange(nq) % nc]).sum(-1)
+    ub = s_ref * 0.95
+    v, i, r = kernels.topk(q.to(torch.bfloat16).to(dev), c.to(torch.bfloat16).to(dev), k, upper_bound=ub.to(dev),
+                           rank_ref=s_ref.to(dev))
+    torch.cuda.synchronize()
+    oracle.check_topk_parity(q, c, v.cpu(), i.cpu(), rtol=2e-5, upper_bound=ub)
+    s = oracle.scores_f32(q, c, fp64=True)
+    gap = (s - s_ref[:, None].double()).abs() > 2e-5 * s_ref[:, None].abs().double()
+    want_lo = ((s > s_ref[:, None].double()) & gap).sum(1)
+    want_hi = ((s > s_ref[:, None].double()) | ~gap).sum(1)
+    assert bool(((r.cpu() >= want_lo) & (r.cpu() <= want_hi)).all())

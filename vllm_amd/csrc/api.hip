@@ -36,7 +36,7 @@ static int check_common(int64_t nq, int64_t nc, int d, int k, int dt) {
 extern "C" size_t abc_topk_workspace_bytes(int64_t nq, int64_t nc, int d, int k, int dtype) {
     if (check_common(nq, nc, d, k, dtype) != ABC_OK) return 0;
     if (nq == 0 || nc == 0) return 16;
-    return sweep_workspace_bytes(nq, nc);
+    return sweep_workspace_bytes(nq, nc, k);
 }
 
 // fill [nq,k] outputs with (-inf, -1): the answer for an empty corpus
@@ -64,7 +64,7 @@ static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const 
     if (!q || !c) return fail(ABC_E_INVALID, "null input pointer");
     if (((uintptr_t)q | (uintptr_t)c) & 15) return fail(ABC_E_INVALID, "q and c must be 16-byte aligned");
     if (dt == ABC_DT_I8 && (!qs || !cs)) return fail(ABC_E_INVALID, "int8 needs q_scale and c_scale");
-    const size_t need = sweep_workspace_bytes(nq, nc);
+    const size_t need = sweep_workspace_bytes(nq, nc, k);
     if (!ws || ws_bytes < need) return abc_fail_ws(need, ws_bytes);
     if ((uintptr_t)ws & 15) return fail(ABC_E_INVALID, "workspace must be 16-byte aligned");
     hipError_t he = hipSuccess;

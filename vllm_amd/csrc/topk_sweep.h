@@ -45,8 +45,8 @@ struct SweepPlan {
     int64_t nq_pad;
 };
 
-void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl);
-size_t sweep_workspace_bytes(int64_t nq, int64_t nc);
+void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl);
+size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k);
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
               int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,

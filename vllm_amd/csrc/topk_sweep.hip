@@ -284,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         const int p_total = (t_end - t_begin) * nph;
         // issue side of the ring runs AHEAD phases in front of the compute side
         int is_tile = t_begin, is_k = 0, is_cnt = 0;
+        int cs_mark = 0;                                   // int8: phases issued when the tile's scales were staged
         __amdgpu_buffer_rsrc_t rc_is = corpus_rsrc(t_begin);
         auto issue_next = [&]() {
             if (is_tile < t_end) {
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                                                             (uint32_t)((left <= 0 ? 0 : (left < 128 ? left : 128)) * 4));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR((char*)cs_lds), 4, lane * 4, 0, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR((char*)cs_lds + 256), 4, lane * 4, 256, 0, 0);
+                cs_mark = is_cnt;
             }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
@@ -430,6 +432,12 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
                 }
             } else refresh = (ti & (ti - 1)) == 0 || ti == 3;
             refresh = refresh && p.n_lists > 1;
+            if constexpr (DT == ABC_DT_I8) {
+                // the tile's scales (2 LDS-DMA pieces issued before this tile's phases) must have landed: they are
+                // older than the 12 youngest operations once 3 phases (4 pieces each) have been issued after them
+                if (is_cnt - cs_mark >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // short rows, or the last tile of the split
+            }
             if (partial) {
                 // the last tile of the corpus: rows past nc (zero-filled by the staging) must never pass or count.
                 // Mask them ONCE here (-inf scores; for int8 a NaN scale below) instead of testing every element.
@@ -825,13 +833,16 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 static int elem_bytes(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 ? 1 : 4); }
 
-void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl) {
+void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl) {
     pl->n_tiles = (int)((nc + TILE - 1) / TILE);
     const int64_t qblocks_total = (nq + TILE - 1) / TILE;
-    // at most 32 query blocks per launch, spread evenly over the launches (98 blocks -> 25+25+24+24, not 32+32+32+2:
-    // a 2-block launch fills 40 of the 256 CUs)
+    // at most 32 query blocks per launch (k <= 64: 8 splits, 16 lists per query) or 16 (k > 64: 16 splits, 32
+    // lists), so that every list publishes its 4th best or better: the tracked bounds are exact down to rank 4
+    // and loose below (int8 10M x 3584, k = 100: +13 %).  Blocks are spread evenly over the launches (98 blocks ->
+    // 25+25+24+24, not 32+32+32+2: a 2-block launch fills 40 of the 256 CUs)
     {
-        const int64_t launches = (qblocks_total + 31) / 32;
+        const int64_t max_qb = k > 64 ? 16 : 32;
+        const int64_t launches = (qblocks_total + max_qb - 1) / max_qb;
         int64_t per = launches > 0 ? (qblocks_total + launches - 1) / launches : 1;
         // multiples of 8 keep the XCD-aware block mapping, which only a long sweep profits from
         if (per > 8 && pl->n_tiles >= 512) per = (per + 7) & ~(int64_t)7;
@@ -850,9 +861,9 @@ void sweep_plan(int64_t nq, int64_t nc, SweepPlan* pl) {
     pl->nq_pad = (int64_t)pl->qblocks_per_launch * TILE;
 }
 
-size_t sweep_workspace_bytes(int64_t nq, int64_t nc) {
+size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k) {
     SweepPlan pl;
-    sweep_plan(nq, nc, &pl);
+    sweep_plan(nq, nc, k, &pl);
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
     return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
 }
@@ -875,7 +886,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
               hipError_t* herr) {
     SweepPlan pl;
-    sweep_plan(nq, nc, &pl);
+    sweep_plan(nq, nc, k, &pl);
     const int rowbytes = d * elem_bytes(dt);
     const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
     uint64_t* cand = (uint64_t*)workspace;
