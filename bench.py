@@ -77,11 +77,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal of the N > 1 path on a one-GPU box: ABC_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # ABC_BENCH_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device)
+    if os.environ.get("ABC_BENCH_WATCHDOG"):              # seconds: dump every thread's stack and exit (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["ABC_BENCH_WATCHDOG"]), exit=True)
+    one_gpu = os.environ.get("ABC_BENCH_ONE_GPU") == "1"
+    backend = os.environ.get("ABC_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vllm_amd import search, parallel, kernels
 
@@ -169,6 +180,14 @@ def main():
                      "flops_per_launch": flops_per_launch},
     }
 
+    if world > 1 and os.environ.get("ABC_BENCH_CHECK") == "1":
+        # rehearsal only: the sharded result of the last step against an unsharded search of the same queries
+        r0, qlast = batches[-1]
+        mu2 = centres(dev, seed)
+        full = search.Embeddings(gen_rows(0, nc, mu2, seed, want_q=False), "bf16", dev)
+        ref_i, ref_v, _ = search.mine_negatives(qlast, full, K, ratio=0.95, offset=r0, fill_masked_tail=False)
+        assert torch.equal(ref_i, out[0]) and torch.equal(ref_v, out[1]), "sharded result differs from the unsharded search"
+        result["rehearsal_check"] = "sharded == unsharded (bit-exact)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(batches[-1], shard, nc, out, dev)
 

@@ -57,13 +57,22 @@ class ShardedCorpus:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
     # -- exchange steps -------------------------------------------------------------------------
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """gloo's all-gather of device tensors never completes on this stack (both ranks sit in wait()),
+        so with a gloo group (rehearsals, CPU-side tests) device tensors are exchanged through host copies.
+        RCCL (backend "nccl", the production path) takes the device tensors as they are."""
+        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
+
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
         if self.world == 1:
             return t.unsqueeze(0)
         # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [world, ...]
+        dev = t.device
+        if self._host_staged(t):
+            t = t.cpu()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out.view((self.world,) + tuple(t.shape))
+        return out.to(dev).view((self.world,) + tuple(t.shape))
 
     def positive_scores(self, q, offset: int) -> torch.Tensor:
         """s_pos[i] = q[i] . corpus[offset + i], replicated on every rank."""
@@ -92,16 +101,20 @@ class ShardedCorpus:
             qc = q if (a == 0 and b == n) else q.rows(a, b)
             ub = None if upper_bound is None else upper_bound[a:b]
             v, i = self.backend.topk(qc, self.shard, k, ub, self.lo)
+            dev = v.device
+            if self._host_staged(v):                        # gloo: the lists cross in host memory
+                v, i = v.cpu(), i.cpu()
             v, i = v.contiguous(), i.contiguous()
             gv = torch.empty((self.world * v.shape[0], k), dtype=v.dtype, device=v.device)
             gi = torch.empty((self.world * i.shape[0], k), dtype=i.dtype, device=i.device)
             wv = dist.all_gather_into_tensor(gv, v, group=self.group, async_op=True)
             wi = dist.all_gather_into_tensor(gi, i, group=self.group, async_op=True)
-            pending.append((wv, wi, gv, gi, v, i))          # v, i stay alive until the collective has read them
+            pending.append((wv, wi, gv, gi, v, i, dev))     # v, i stay alive until the collective has read them
         outs_v, outs_i = [], []
-        for wv, wi, gv, gi, v, i in pending:
+        for wv, wi, gv, gi, v, i, dev in pending:
             wv.wait()
             wi.wait()
+            gv, gi = gv.to(dev), gi.to(dev)
             mv, mi = self.backend.merge(gv.view(self.world, v.shape[0], k), gi.view(self.world, i.shape[0], k))
             outs_v.append(mv)
             outs_i.append(mi)
