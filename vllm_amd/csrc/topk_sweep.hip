@@ -165,9 +165,21 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         const int swz = (lane >> 4) & 3;                  // == (row >> 2) & 3
         voff[i] = row * rowbytes + (((lane & 3) ^ swz) << 4);
     }
+    const int voff_p[2] = {wave * 2048 + lane * 16, wave * 2048 + 1024 + lane * 16};
     const int64_t q_rows_left = p.nq - qrow0;
     const uint32_t q_bytes = (uint32_t)((q_rows_left < TILE ? q_rows_left : TILE) * rowbytes);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + qrow0 * rowbytes, q_bytes);
+#ifdef ABC_PHASE_STAMPS                                            // diagnostic build: where the staging traffic is served from
+    const bool same_q = (p.debug_flags & 32768) != 0;              // every workgroup stages query block 0
+    const bool same_c = (p.debug_flags & 65536) != 0;              // every workgroup stages corpus tile 0
+#else
+    constexpr bool same_q = false, same_c = false;
+#endif
+#ifdef ABC_PHASE_STAMPS
+    const bool packed_t = (p.debug_flags & 131072) != 0;           // TIMING ONLY: phase-major operand addressing (wrong data)
+#else
+    constexpr bool packed_t = false;
+#endif
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(p.q + (same_q ? 0 : qrow0) * rowbytes, q_bytes);
 
     // fragment read offsets: row (l31) of the wave's sub-tile, chunk (2s+h) ^ ((l31>>2)&3)
     const int swz_r = (l31 >> 2) & 3;
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
 
     // ---- software pipeline over (tile, kstep) -----------------------------------------------------
     auto corpus_rsrc = [&](int tile) {
-        const int64_t r0 = (int64_t)tile * TILE;
+        const int64_t r0 = same_c ? 0 : (int64_t)tile * TILE;
         const int64_t left = p.nc - r0;
         return make_rsrc(p.c + r0 * rowbytes, (uint32_t)((left < TILE ? left : TILE) * rowbytes));
     };
@@ -385,6 +397,8 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
         READ_FRAGS(a1, b1, sb, 1);                                                                           \
         if (!no_dma) {                                                                                       \
             if (FAST) {                                                                                      \
+                if (packed_t) stage_issue(rc_is, rq, smem, (ph + 3) & (N_SLOTS - 1), wave, voff_p, (kk + 3) * STAGE_BYTES); \
+                else                                                                                         \
                 stage_issue(rc_is, rq, smem, (ph + 3) & (N_SLOTS - 1), wave, voff, (kk + 3) * ROWB);         \
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                             \
             } else {                                                                                         \
