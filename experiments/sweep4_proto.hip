@@ -142,6 +142,99 @@ __device__ __forceinline__ void sweep4_body(char* smem, const char* __restrict__
                                                               __builtin_bit_cast(v8s, FB[nb]), acc[mb][nb], 0, 0, 0);
 #endif
 
+#ifdef STAGE_VGPR
+    // TIMING ONLY (phase-major addressing, wrong data): operands go global -> VGPR (four register sets, loaded four
+    // phases ahead) -> ds_write_b128 into a ring of TWO LDS slots, instead of LDS-DMA.  Two shorter instructions per
+    // 1 KB piece, each of which may fit into the 32-clock gap between two MFMAs.
+    if (t_begin < t_end) {
+        v4i S0[8], S1[8], S2[8], S3[8];
+        int lk = 0, lcbase = 0;
+#define LOADSET(S)                                                                                               \
+    {                                                                                                            \
+        const int so_ = lcbase + lk * STAGE_BYTES + wave * 4096, sq_ = lk * STAGE_BYTES + wave * 4096;           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            S[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rc, lane * 16, so_ + i * 1024, 0)); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            S[4 + i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rq, lane * 16, sq_ + i * 1024, 0)); \
+        if (++lk == nph) {                                                                                       \
+            lk = 0;                                                                                              \
+            lcbase += TILE * rowbytes;                                                                           \
+        }                                                                                                        \
+    }
+#define WRITESET(S, SLOTOFF)                                                                                     \
+    {                                                                                                            \
+        char* d_ = smem + (SLOTOFF) + wave * 4096 + lane * 16;                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v4i*)(d_ + i * 1024) = S[i];                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) *(v4i*)(d_ + STAGE_BYTES + i * 1024) = S[4 + i];            \
+    }
+        LOADSET(S0);
+        LOADSET(S1);
+        LOADSET(S2);
+        LOADSET(S3);
+        WRITESET(S0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        v4i a0[4], b0[4], a1[4], b1[4];
+        READ_A(a0, smem, 0);
+        READ_B(b0, smem, 0);
+#define PHASEV(SW, SL, CUR, NXT)                                                                                 \
+    {                                                                                                            \
+        READ_A(a1, smem + (CUR), 1);                                                                             \
+        READ_B(b1, smem + (CUR), 1);                                                                             \
+        WRITESET(SW, NXT);                                                                                       \
+        MMA(a0, b0);                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                   \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+        __builtin_amdgcn_s_barrier();                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        READ_A(a0, smem + (NXT), 0);                                                                             \
+        READ_B(b0, smem + (NXT), 0);                                                                             \
+        LOADSET(SL);                                                                                             \
+        MMA(a1, b1);                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+        }                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                   \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }
+        for (int tile = t_begin; tile < t_end; ++tile) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0;
+            for (int kk = 0; kk < nph; kk += 4) {              // phase j: register set j % 4, LDS slot j % 2
+                PHASEV(S1, S0, 0, SLOT_BYTES);
+                PHASEV(S2, S1, SLOT_BYTES, 0);
+                PHASEV(S3, S2, 0, SLOT_BYTES);
+                PHASEV(S0, S3, SLOT_BYTES, 0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float x;
+                        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(acc[mb][nb][r]));
+                        best[nb] = fmaxf(best[nb], x);
+                    }
+        }
+    }
+#else
     if (t_begin < t_end) {
         issue();
         issue();
@@ -228,6 +321,7 @@ __device__ __forceinline__ void sweep4_body(char* smem, const char* __restrict__
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#endif
     if (tid == 0) {
         stats[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0c;          // shader clocks
         stats[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - t0r;  // 100 MHz ticks

@@ -27,7 +27,7 @@ struct SweepParams {
                             //   1      contraction only, no epilogue       2      quick reject only, nothing appended
                             //   8      never refresh the shared bounds     16     debug counters + cycle stamps to stderr
                             //   bits 8-9   refresh spacing 5/4 (0), 9/8, 3/2, 2
-                            //   bits 12-13 XCD groups sharing query blocks: 4 (0), 1, 2, 8
+                            //   bits 12-13 XCDs that share a group of query blocks: 2 (0, default), 1, 4, 8
                             //   16384  (-DABC_PHASE_STAMPS build only) no staging: the LDS-read + MFMA ceiling
                             // ABC_PLAN_QB=<n> overrides the query blocks per launch; ABC_LIB picks another .so (A/B runs)
     int n_lists;            // 2 * n_splits candidate lists per query

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(512, 2) void topk_sweep_kernel(const SweepParams p)
             // g XCDs share a group of per*g query blocks and take n_splits/g splits each (g = 1: an XCD sweeps
             // the whole corpus for 'per' query blocks)
             const int gsel = (p.debug_flags >> 12) & 3;
-            int g = gsel == 0 ? 4 : gsel == 1 ? 1 : gsel == 2 ? 2 : 8;
+            // g = 2: 8 query blocks x 4 splits per XCD, the pair with the fewest distinct operand bytes per phase
+            // beyond L2 (+3 % over g = 4 on the mining shape, measured; int8 with 16 blocks per launch: equal)
+            int g = gsel == 0 ? 2 : gsel == 1 ? 1 : gsel == 2 ? 4 : 8;
             if (p.n_splits % g) g = 1;
             const int per = (p.n_qblocks >> 3) * g;
             const int x = id & 7, j = id >> 3;
