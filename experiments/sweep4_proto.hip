@@ -16,6 +16,9 @@
 #define STAGE_BYTES (TILE * ROWB)
 #define SLOT_BYTES (2 * STAGE_BYTES)
 #define N_SLOTS 4
+#ifndef DMA_SZ
+#define DMA_SZ 16          /* -DDMA_SZ=4: same instruction count, a quarter of the bytes (timing only) */
+#endif
 #define RING_BYTES (N_SLOTS * SLOT_BYTES)
 
 #define CHECK(x)                                                                       \
@@ -103,11 +106,11 @@ __device__ __forceinline__ void sweep4_body(char* smem, const char* __restrict__
             const int so = is_cbase + is_k * STAGE_BYTES + wave * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, LDS_PTR(dst + i * 1024), 16, lane * 16, so + i * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, LDS_PTR(dst + i * 1024), DMA_SZ, lane * 16, so + i * 1024, 0, 0);
             const int sq = is_k * STAGE_BYTES + wave * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(dst + STAGE_BYTES + i * 1024), 16, lane * 16, sq + i * 1024, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, LDS_PTR(dst + STAGE_BYTES + i * 1024), DMA_SZ, lane * 16, sq + i * 1024, 0, 0);
         }
 #else
         {
