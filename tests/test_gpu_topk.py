@@ -13,6 +13,17 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=["auto", "sweep4"])
+def sweep_kernel(request, monkeypatch):
+    """Every test of this file runs twice: with the kernel the library picks by sweep length (the 8-wave one at
+    these sizes) and with the one-wave-per-SIMD kernel forced (ABC_SWEEP4=1, read at every launch)."""
+    if request.param == "sweep4":
+        monkeypatch.setenv("ABC_SWEEP4", "1")
+    else:
+        monkeypatch.delenv("ABC_SWEEP4", raising=False)
+    return request.param
+
+
 def _run(q, c, k, **kw):
     from vllm_amd import kernels
     dev = _dev()

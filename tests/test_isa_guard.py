@@ -21,13 +21,15 @@ def isa(tmp_path_factory):
         pytest.skip("hipcc not on PATH")
     out = tmp_path_factory.mktemp("isa") / "topk_sweep.s"
     subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-value",
+                    "-mllvm", "-pragma-unroll-threshold=200000",      # as vllm_amd/csrc/Makefile
                     "-S", "--cuda-device-only", SRC, "-o", str(out)], check=True, cwd=os.path.dirname(SRC),
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out.read_text()
 
 
-def _kernel(isa_text, dt, count):
-    name = f"_Z17topk_sweep_kernelILi{dt}ELb{count}EEv11SweepParams"
+def _kernel(isa_text, dt, count, four_wave=False):
+    name = (f"_Z18topk_sweep4_kernelILi{dt}ELb{count}EEv11SweepParams" if four_wave
+            else f"_Z17topk_sweep_kernelILi{dt}ELb{count}EEv11SweepParams")
     m = re.search(rf"^{name}:[^\n]*\n(.*?)s_endpgm", isa_text, re.S | re.M)
     assert m, name
     return m.group(1)
@@ -64,3 +66,24 @@ def test_main_variants_do_not_spill_vectors(isa):
     for dt in (0, 1, 2):
         body = _kernel(isa, dt, 0)
         assert "scratch_" not in body, f"dtype {dt}: vector spills in the mining/search variant"
+
+
+@pytest.mark.parametrize("dt,mfma,per_phase", [(0, "v_mfma_f32_32x32x16_bf16", 64), (1, "v_mfma_i32_32x32x32_i8", 64),
+                                               (2, "v_mfma_f32_32x32x2_f32", 256)])
+def test_four_wave_phase_loop_is_clean(isa, dt, mfma, per_phase):
+    """topk_sweep4_kernel (one wave per SIMD): the phase loop is two basic blocks (steps 1-3 with the barrier, then
+    step 0).  Per 128-byte phase: 32 fragment reads, 16 LDS-DMA pieces, ONE vmcnt wait (the explicit vmcnt(0) before
+    the barrier) -- hipcc once added vmcnt(0)/(1) in step 0, a wait for the pieces issued one step earlier, when the
+    epilogue's loads were not declared complete -- no scratch traffic, accumulators in AGPRs."""
+    body = _kernel(isa, dt, 0, four_wave=True)
+    assert "scratch_" not in body, "the accumulators (or spills) went to scratch: is the unroll threshold flag set?"
+    blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
+    loop = [b for b in blocks if mfma in b]
+    assert len(loop) == 2, [b.count(mfma) for b in loop]
+    text = "".join(loop)
+    assert text.count(mfma) == per_phase
+    assert text.count("ds_read_b128") == 32
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", text)) == 16
+    assert len(re.findall(r"^\s*s_barrier", text, re.M)) == 1
+    assert re.findall(r"s_waitcnt vmcnt\((\d+)\)", text) == ["0"]
+    assert re.search(mfma + r" a\[", text), "accumulators not in AGPRs"

@@ -888,8 +888,31 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k) {
     return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
 }
 
+#include "topk_sweep4.inc"
+
+// Which sweep kernel a launch takes.  Both produce the same lists and the same result; the one-wave-per-SIMD kernel
+// (topk_sweep4.inc) is 2 % faster on long sweeps (mining shape: 1611 tiles per split; int8 10 M: +1.6 %) and slower
+// on short ones (412 k rows per shard: -1 %; eval-sized corpora: its first-tile work is twice as large per wave).
+// ABC_SWEEP4=0 / 1 forces one of them (tests run both).
+static bool use_sweep4(const SweepParams& p) {
+    const char* e = getenv("ABC_SWEEP4");
+    if (e && *e) return atoi(e) != 0;
+    return p.n_tiles / (p.n_splits > 0 ? p.n_splits : 1) >= 512;
+}
+
 template <int DT, bool COUNT>
 static hipError_t launch_sweep(const SweepParams& p, int grid, hipStream_t st) {
+    if (use_sweep4(p)) {
+        static bool attr4_set = false;
+        auto kern4 = topk_sweep4_kernel<DT, COUNT>;
+        if (!attr4_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)kern4, hipFuncAttributeMaxDynamicSharedMemorySize, S4_LDS);
+            if (e != hipSuccess) return e;
+            attr4_set = true;
+        }
+        hipLaunchKernelGGL(kern4, dim3(grid), dim3(256), S4_LDS, st, p);
+        return hipGetLastError();
+    }
     static bool attr_set = false;
     auto kern = topk_sweep_kernel<DT, COUNT>;
     if (!attr_set) {
