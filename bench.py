@@ -175,7 +175,7 @@ def main():
                    "queries_per_step": bq, "corpus_rows": nc, "d": D, "k": K, "parallelism": f"corpus-shard{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "kernel": "topk_sweep_kernel<bf16>", "avg_launch_ms": sweep_avg_ms / launches_per_step,
+                     "kernel": sweep_kernel_name(hi - lo), "avg_launch_ms": sweep_avg_ms / launches_per_step,
                      "sweep_ms_per_step": sweep_avg_ms,
                      "flops_per_launch": flops_per_launch},
     }
@@ -195,6 +195,15 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def sweep_kernel_name(rows):
+    """Which sweep kernel libabcsearch takes for a shard of `rows` rows at this bench's 8192 queries per launch
+    (32 query blocks x 8 splits): the rule of use_sweep4() in vllm_amd/csrc/topk_sweep.hip, restated for the label."""
+    tiles = (rows + 255) // 256
+    forced = os.environ.get("ABC_SWEEP4", "")
+    four = (forced != "0") if forced else tiles // 8 >= 512
+    return "topk_sweep4_kernel<bf16>" if four else "topk_sweep_kernel<bf16>"
 
 
 def cpu_baseline(batch, shard, nc, gpu_out, dev):
