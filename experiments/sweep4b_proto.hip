@@ -201,14 +201,10 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
 #endif
                 MMA(a1, b1);
 #if defined(BOTH_IN_STEP3) && !defined(NO_DMA)
+                // all 8 fragment reads first (a burst), then one piece behind every MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 16; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
