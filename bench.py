@@ -202,7 +202,7 @@ def sweep_kernel_name(rows):
     (32 query blocks x 8 splits): the rule of use_sweep4() in vllm_amd/csrc/topk_sweep.hip, restated for the label."""
     tiles = (rows + 255) // 256
     forced = os.environ.get("ABC_SWEEP4", "")
-    four = (forced != "0") if forced else tiles // 8 >= 512
+    four = (forced != "0") if forced else tiles // 8 >= 384
     return "topk_sweep4_kernel<bf16>" if four else "topk_sweep_kernel<bf16>"
 
 

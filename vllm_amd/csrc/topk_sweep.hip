@@ -891,13 +891,13 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k) {
 #include "topk_sweep4.inc"
 
 // Which sweep kernel a launch takes.  Both produce the same lists and the same result; the one-wave-per-SIMD kernel
-// (topk_sweep4.inc) is 2 % faster on long sweeps (mining shape: 1611 tiles per split; int8 10 M: +1.6 %) and slower
+// (topk_sweep4.inc) is 1-2 % faster on long sweeps (mining shape, 1611 tiles per split: +2 %; 402: +0.5 %; int8 10 M: +1.6 %) and slower
 // on short ones (412 k rows per shard: -1 %; eval-sized corpora: its first-tile work is twice as large per wave).
 // ABC_SWEEP4=0 / 1 forces one of them (tests run both).
 static bool use_sweep4(const SweepParams& p) {
     const char* e = getenv("ABC_SWEEP4");
     if (e && *e) return atoi(e) != 0;
-    return p.n_tiles / (p.n_splits > 0 ? p.n_splits : 1) >= 512;
+    return p.n_tiles / (p.n_splits > 0 ? p.n_splits : 1) >= 384;
 }
 
 template <int DT, bool COUNT>
