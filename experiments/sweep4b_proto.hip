@@ -141,7 +141,9 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
         __builtin_amdgcn_s_barrier();
         v4i a0[4], b0[4], a1[4], b1[4];
         READ_A(a0, smem, 0);
+#ifndef SPLIT_WAIT
         READ_B(b0, smem, 0);
+#endif
 #ifndef NO_DMA
         ISSUE_HALF(0);                                         // corpus pieces of phase 1
 #ifdef BOTH_IN_STEP3
@@ -162,6 +164,11 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
                 const char* sn = smem + ((ph + 1) & 1) * SLOT_BYTES;
                 // step 0: reads of step 1; query pieces of phase ph+1 -> the other slot (its corpus pieces went out in
                 // step 3 of the phase before: that slot has been free since the barrier of step 2 there)
+#ifdef SPLIT_WAIT
+                // the query operand of THIS phase became visible at the barrier that ended the phase before: its step-0
+                // fragments are read here, right before their first use (exposed LDS latency, one more step of flight)
+                READ_B(b0, sb, 0);
+#endif
                 READ_A(a1, sb, 1);
                 READ_B(b1, sb, 1);
 #if !defined(NO_DMA) && !defined(BOTH_IN_STEP3)
@@ -169,6 +176,9 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
                 ISSUE_ADVANCE();
 #endif
                 MMA(a0, b0);
+#ifdef SPLIT_WAIT
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#endif
 #if !defined(NO_DMA) && !defined(BOTH_IN_STEP3)
                 SCHED(1);
 #else
@@ -185,13 +195,19 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
                 READ_B(b1, sb, 3);
                 MMA(a0, b0);
                 SCHED(0);
+#ifdef SPLIT_WAIT
+                asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // the corpus pieces of ph+1 (the query pieces may fly on)
+#else
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // step 3: reads of step 0 of phase ph+1; corpus pieces of phase ph+2 -> this phase's slot, which nobody
                 // reads any more (every wave's reads had returned before the barrier)
                 READ_A(a0, sn, 0);
+#ifndef SPLIT_WAIT
                 READ_B(b0, sn, 0);
+#endif
 #ifndef NO_DMA
                 ISSUE_HALF(0);
 #ifdef BOTH_IN_STEP3
@@ -213,6 +229,11 @@ __device__ __forceinline__ void sweep4b_body(char* smem, const char* __restrict_
                 SCHED(1);
 #else
                 SCHED(0);
+#endif
+#ifdef SPLIT_WAIT
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                // the query pieces of ph+1 (issued before the corpus pieces of ph+2)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
 #endif
             }
 #pragma unroll
