@@ -58,8 +58,9 @@ class ShardedCorpus:
 
     # -- exchange steps -------------------------------------------------------------------------
     def _host_staged(self, t: torch.Tensor) -> bool:
-        """gloo's all-gather of device tensors never completes on this stack (both ranks sit in wait()),
-        so with a gloo group (rehearsals, CPU-side tests) device tensors are exchanged through host copies.
+        """gloo's collectives on device tensors do not complete reliably on this stack (all-gather: both ranks sit in
+        wait(); all-reduce: hangs with four ranks on one GPU), so with a gloo group (rehearsals, CPU-side tests)
+        device tensors are exchanged through host copies.
         RCCL (backend "nccl", the production path) takes the device tensors as they are."""
         return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
 
@@ -84,7 +85,12 @@ class ShardedCorpus:
             s[a - offset:b - offset] = self.backend.rowdot(q.rows(a - offset, b - offset),
                                                            self.shard.rows(a - self.lo, b - self.lo))
         if self.world > 1:
-            dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged(s):                        # gloo: through host memory (see _host_staged)
+                h = s.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                s = h.to(dev)
+            else:
+                dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)
         return s
 
     def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None, chunk: int = 8192
