@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nc", type=int, default=NC_FULL, help="corpus rows (default: the 3.3M of BASELINE.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-job", action="store_true",
+                    help="time the WHOLE mining job (every corpus row is a query: 3.3M queries, about 70 s on one GPU) "
+                         "instead of --steps batches of it; --steps is then derived from the corpus size")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,11 +120,22 @@ def main():
     corpus.backend.topk = timed_topk
 
     bq = QUERIES_PER_GPU_STEP * world
-    n_batches = args.steps + args.warmup
     batches = []
-    for s in range(n_batches):
-        r0 = (s * bq) % max(nc - bq, 1)
-        batches.append((r0, search.Embeddings(gen_rows(r0, r0 + bq, mu, seed, want_q=True), "bf16", dev)))
+    if args.full_job:
+        # every row of the pair table is a query (create_negative_index.py:37): all of them resident in HBM (27 GB
+        # at the full size) before the clock starts, one step per bq of them, the last one ragged
+        args.steps = (nc + bq - 1) // bq
+        all_q = search.Embeddings(gen_rows(0, nc, mu, seed, want_q=True), "bf16", dev)
+        for s in range(args.warmup):
+            batches.append((0, all_q.rows(0, min(bq, nc))))
+        for s in range(args.steps):
+            batches.append((s * bq, all_q.rows(s * bq, min((s + 1) * bq, nc))))
+    else:
+        for s in range(args.steps + args.warmup):
+            r0 = (s * bq) % max(nc - bq, 1)
+            batches.append((r0, search.Embeddings(gen_rows(r0, r0 + bq, mu, seed, want_q=True), "bf16", dev)))
+    n_batches = len(batches)
+    n_queries = sum(b[1].shape[0] for b in batches[args.warmup:])
     del mu
 
     def step(s):
@@ -150,21 +164,26 @@ def main():
 
     # per step: every sweep launch of the step (N > 1 sweeps the step's queries in chunks of 8192)
     sweep_avg_ms = sum(a.elapsed_time(b) for a, b in sweep_ms) / max(args.steps, 1)
-    flops_per_step = 2.0 * bq * (hi - lo) * D            # algorithmic: 2*Nc_local*D per query
+    flops_per_step = 2.0 * (n_queries / max(args.steps, 1)) * (hi - lo) * D   # algorithmic: 2*Nc_local*D per query
     achieved = flops_per_step / (sweep_avg_ms * 1e-3) / 1e12
     launches_per_step = max(len(sweep_ms) // max(args.steps, 1), 1)
     flops_per_launch = flops_per_step / launches_per_step
-    traffic = None
-    tfile = os.path.join(ROOT, "bench_traffic.json")      # PMC result of the last profiled run (profiles/)
+    # HBM/fabric bytes per launch: PMC counters need rocprofv3 passes of their own (scripts/profile_round.sh), so
+    # this run can only CARRY OVER the figure of the last profiled run of the same kernel and shape, and says so
+    traffic, traffic_source = None, "not measured in this run (no PMC pass)"
+    tfile = os.path.join(ROOT, "bench_traffic.json")
     if os.path.exists(tfile) and world == 1 and nc == NC_FULL:
         try:
-            traffic = json.load(open(tfile)).get("sweep_hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("sweep_hbm_bytes_per_launch")
+            traffic_source = ("carried over from " + str(tj.get("source", "bench_traffic.json")) +
+                              ": FETCH_SIZE x 2 of a separate rocprofv3 --pmc pass, NOT measured in this run")
         except Exception:
             traffic = None
 
     result = {
         "metric": "queries/sec exact top-64 over 3.3M x 4096 bf16 corpus",
-        "value": bq * args.steps / dt,
+        "value": n_queries / dt,
         "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
@@ -172,9 +191,13 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"CC3M hard-negative mining (BASELINE configs[2]): corpus {nc} x {D} bf16 row-sharded over "
                                f"{world} GPU(s), {bq} queries/step, k={K}, 0.95-positive upper bound",
-                   "queries_per_step": bq, "corpus_rows": nc, "d": D, "k": K, "parallelism": f"corpus-shard{world}"},
+                   "queries_per_step": bq, "corpus_rows": nc, "d": D, "k": K, "parallelism": f"corpus-shard{world}",
+                   "queries_timed": n_queries,
+                   "job": ("the full job: every one of the corpus rows as a query" if args.full_job else
+                           f"{n_queries} queries of the {nc}-query job timed; the job's rate follows from the per-step rate "
+                           "(every step sweeps the whole corpus; --full-job times all of it)")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": sweep_kernel_name(hi - lo), "avg_launch_ms": sweep_avg_ms / launches_per_step,
                      "sweep_ms_per_step": sweep_avg_ms,
                      "flops_per_launch": flops_per_launch},
@@ -185,7 +208,7 @@ def main():
         r0, qlast = batches[-1]
         mu2 = centres(dev, seed)
         full = search.Embeddings(gen_rows(0, nc, mu2, seed, want_q=False), "bf16", dev)
-        ref_i, ref_v, _ = search.mine_negatives(qlast, full, K, ratio=0.95, offset=r0, fill_masked_tail=False)
+        ref_i, ref_v, _ = search.mine_negatives(qlast, full, K, ratio=0.95, offset=r0)
         assert torch.equal(ref_i, out[0]) and torch.equal(ref_v, out[1]), "sharded result differs from the unsharded search"
         result["rehearsal_check"] = "sharded == unsharded (bit-exact)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -201,8 +224,9 @@ def sweep_kernel_name(rows):
     """Which sweep kernel libabcsearch takes for a shard of `rows` rows at this bench's 8192 queries per launch
     (32 query blocks x 8 splits): the rule of use_sweep4() in vllm_amd/csrc/topk_sweep.hip, restated for the label."""
     tiles = (rows + 255) // 256
-    forced = os.environ.get("ABC_SWEEP4", "")
-    four = (forced != "0") if forced else tiles // 8 >= 384
+    from vllm_amd import kernels
+    forced = kernels.debug_get("sweep4")                  # -1: by sweep length
+    four = bool(forced) if forced >= 0 else tiles // 8 >= 384
     return "topk_sweep4_kernel<bf16>" if four else "topk_sweep_kernel<bf16>"
 
 

@@ -87,6 +87,9 @@ int abc_topk_i8(const void* q, const float* q_scale, int64_t nq, const void* c, 
 /*
  * out[i] = dot(q[i,:], c[i,:]) in fp32, i < n.  Replaces scores[idx] of
  * pretrain/create_negative_index.py:48 and the bmm of visualization/neg_mine.py:32-35.
+ * For every shape abc_topk_* accepts (d*sizeof(elem) % 128 == 0) the value is contracted by the same MFMA
+ * instruction, fragments and k order as the sweep, i.e. it is BIT-IDENTICAL to the score abc_topk_* sees for
+ * column i of query i -- the reference takes scores[idx] out of the same GEMV it masks (:47-49).
  */
 int abc_rowdot_bf16(const void* q, const void* c, int64_t n, int d, float* out, void* stream);
 int abc_rowdot_f32(const void* q, const void* c, int64_t n, int d, float* out, void* stream);
@@ -97,9 +100,24 @@ int abc_rowdot_i8(const void* q, const float* q_scale, const void* c, const floa
  * Merge `parts` sorted top-k lists per query into one (the cross-shard / cross-GPU merge after the
  * all-gather; no counterpart in the reference, whose search is single-GPU).
  *   vals [parts,nq,k] f32, idx [parts,nq,k] i64 (already global, -1 = missing) -> out_val/out_idx [nq,k]
+ *   idx_limit   exclusive upper bound of the indices in idx (the caller's total row count).  The merge packs
+ *               (score, index) into 64-bit keys with a 32-bit index field: idx_limit > 2^32-1 is rejected
+ *               (ABC_E_INVALID) instead of wrapping silently.
  */
-int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k,
+int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, int64_t idx_limit,
                    float* out_val, int64_t* out_idx, void* stream);
+
+/*
+ * Diagnostics hook for tests and timing scripts (no counterpart in the reference; not for production use: it
+ * changes process-wide settings, do not call it while another thread is inside abc_topk_*):
+ *   "sweep4"  -1 pick the sweep kernel by sweep length (default), 0 / 1 force the 8-wave / one-wave-per-SIMD kernel
+ *   "flags"   SweepParams::debug_flags (cycle stamps, refresh spacing, XCD grouping; result-altering bits are
+ *             masked out unless the library was built with -DABC_DIAG)
+ *   "plan_qb" query blocks per launch (0 = the library's plan)
+ * The same knobs are read from ABC_SWEEP4 / ABC_DEBUG_FLAGS / ABC_PLAN_QB once, when the library is loaded.
+ */
+int abc_debug_set(const char* name, int64_t value);
+int64_t abc_debug_get(const char* name);
 
 /*
  * Symmetric per-vector absmax int8 quantiser: scale = max|x|/127 (1 for an all-zero

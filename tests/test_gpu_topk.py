@@ -14,14 +14,14 @@ def _dev():
 
 
 @pytest.fixture(autouse=True, params=["auto", "sweep4"])
-def sweep_kernel(request, monkeypatch):
+def sweep_kernel(request):
     """Every test of this file runs twice: with the kernel the library picks by sweep length (the 8-wave one at
-    these sizes) and with the one-wave-per-SIMD kernel forced (ABC_SWEEP4=1, read at every launch)."""
-    if request.param == "sweep4":
-        monkeypatch.setenv("ABC_SWEEP4", "1")
-    else:
-        monkeypatch.delenv("ABC_SWEEP4", raising=False)
-    return request.param
+    these sizes) and with the one-wave-per-SIMD kernel forced (abc_debug_set "sweep4"; the environment is only
+    read when the library is loaded)."""
+    from vllm_amd import kernels
+    kernels.debug_set("sweep4", 1 if request.param == "sweep4" else -1)
+    yield request.param
+    kernels.debug_set("sweep4", -1)
 
 
 def _run(q, c, k, **kw):

@@ -33,7 +33,7 @@ def test_argument_errors_without_gpu():
     assert lib.abc_topk_workspace_bytes(10, 10, 64, 129, _lib.DT_BF16) == 0        # k too large
     assert lib.abc_topk_workspace_bytes(8192, 3_300_000, 4096, 64, _lib.DT_BF16) > 0
     assert lib.abc_topk_bf16(None, 4, None, 4, 64, 5, None, 0, None, None, None, _lib.NO_SELF, None, None, 0, None) == -1
-    assert lib.abc_topk_merge(None, None, 0, 4, 5, None, None, None) == -1
+    assert lib.abc_topk_merge(None, None, 0, 4, 5, 100, None, None, None) == -1
     assert lib.abc_infonce_workspace_bytes(8, 4, 64) == 0                           # C < B
     assert lib.abc_infonce_workspace_bytes(128, 1024, 4096) > 0
 
@@ -77,6 +77,9 @@ class _Emb:
     def rows(self, lo, hi):
         return _Emb(self.data[lo:hi])
 
+    def take(self, index):
+        return _Emb(self.data[index])
+
 
 def _worker(rank, world, port, ret):
     import oracle
@@ -86,13 +89,14 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     q, c = oracle.make_clustered(40, 301, 64, seed=6, n_centres=4)
     c[100] = c[200]                                                     # a tie across two shards
+    c[8] = -q[5]                                                        # noisy pair (row 3+5): s_pos = -1, only the positive survives
     lo, hi = parallel.shard_bounds(c.shape[0], world, rank)
 
     def _topk(qe, ce, k, ub, off):
         v, i = oracle.topk_ref(qe.data, ce.data, k, upper_bound=ub)
         return v, torch.where(i >= 0, i + off, i)
 
-    def _merge(vals, idx):
+    def _merge(vals, idx, idx_limit=None):
         parts, nq, k = vals.shape
         v = vals.permute(1, 0, 2).reshape(nq, parts * k)
         i = idx.permute(1, 0, 2).reshape(nq, parts * k)
@@ -104,11 +108,12 @@ def _worker(rank, world, port, ret):
 
     be = parallel.Backend(topk=_topk, rowdot=lambda a, b: (a.data * b.data).sum(-1), merge=_merge)
     sc = parallel.ShardedCorpus(_Emb(c[lo:hi]), lo, c.shape[0], backend=be)
-    idx, vals, s_pos = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3)
+    idx, vals, s_pos = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3, fill_masked_tail=False)
     # chunked + overlapped exchange gives the same lists as one exchange
     v2, i2 = sc.topk(_Emb(q), 16, upper_bound=s_pos * 0.95, chunk=16)
     assert torch.equal(i2, idx) and torch.equal(v2, vals)
-    ret[rank] = (idx, vals, s_pos)
+    filled, _, _ = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3)     # the driver's form: tail filled
+    ret[rank] = (idx, vals, s_pos, filled)
     dist.destroy_process_group()
 
 
@@ -120,12 +125,26 @@ def test_sharded_mining_exchange_gloo(world):
     mp.spawn(_worker, args=(world, 29650 + world, ret), nprocs=world, join=True)
     q, c = oracle.make_clustered(40, 301, 64, seed=6, n_centres=4)
     c[100] = c[200]
+    c[8] = -q[5]
     s_pos = (q * c[3:43]).sum(-1)
     rv, ri = oracle.topk_ref(q, c, 16, upper_bound=s_pos * 0.95)
+    assert int((ri[5] < 0).sum()) > 0                                            # the noisy pair leaves holes
+    # N = 1 reference of the filled form: the unsharded helper on the whole corpus (N = 1 and N > 1 must agree)
+    from vllm_amd import parallel
+    from vllm_amd.search import fill_masked_tail_rows
+    want = ri.clone()
+    fill_masked_tail_rows(want, s_pos * 0.95, lambda rows: oracle.topk_ref(q[rows], c, 16))
+    assert bool((want >= 0).all()) and all(len(set(r.tolist())) == 16 for r in want)
+    sc1 = parallel.ShardedCorpus(_Emb(c), 0, c.shape[0], backend=parallel.Backend(
+        topk=lambda qe, ce, k, ub, off: oracle.topk_ref(qe.data, ce.data, k, upper_bound=ub), rowdot=lambda a, b: (a.data * b.data).sum(-1),
+        merge=None))
+    one, _, _ = sc1.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3)             # world 1 through the same class
+    assert torch.equal(one, want)
     for r in range(world):
-        idx, vals, sp = ret[r]
+        idx, vals, sp, filled = ret[r]
         assert torch.allclose(sp, s_pos, atol=1e-6)
         assert torch.equal(idx, ri) and torch.allclose(vals, rv, atol=1e-6)      # replicated and exact on every rank
+        assert torch.equal(filled, want)                                         # same lists at every world size
 
 
 def _gather_grad_worker(rank, world, port, ret):
@@ -160,3 +179,49 @@ def test_differentiable_gather_gloo(world):
             slot = gathered_column_order(s_rank, world).index(r)
             want += ret[s_rank][2][slot * 3:(slot + 1) * 3]
         assert torch.allclose(grad, want, atol=1e-6)
+
+
+def test_merge_rejects_indices_beyond_32_bits():
+    """The merge packs indices into a 32-bit field: it refuses, before any launch, instead of wrapping."""
+    from vllm_amd import _lib, parallel
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(16)                     # never dereferenced: the argument check comes first
+    assert lib.abc_topk_merge(dummy, dummy, 2, 4, 5, (1 << 32), dummy, dummy, None) == -1
+    assert b"idx_limit" in lib.abc_last_error()
+    assert lib.abc_topk_merge(dummy, dummy, 2, 4, 5, -1, dummy, dummy, None) == -1
+    with pytest.raises(ValueError):
+        parallel.ShardedCorpus(_Emb(torch.zeros(4, 8)), 0, 1 << 32, backend=parallel.Backend(None, None, None))
+    parallel.ShardedCorpus(_Emb(torch.zeros(4, 8)), 0, (1 << 32) - 2, backend=parallel.Backend(None, None, None))
+
+
+def test_debug_knobs_are_process_state_not_environment(monkeypatch):
+    """ABC_* variables are read once, when the library is loaded: changing the environment afterwards does nothing;
+    abc_debug_set is the only way to change a knob, and result-altering flag bits are masked in a production build."""
+    from vllm_amd import kernels
+    before = kernels.debug_get("sweep4")
+    monkeypatch.setenv("ABC_SWEEP4", "1" if before != 1 else "0")
+    monkeypatch.setenv("ABC_DEBUG_FLAGS", "3")
+    assert kernels.debug_get("sweep4") == before and kernels.debug_get("flags") & 3 == 0
+    try:
+        kernels.debug_set("sweep4", 1)
+        assert kernels.debug_get("sweep4") == 1
+        kernels.debug_set("flags", 1 | 2 | 16)
+        assert kernels.debug_get("flags") == 16            # 1 and 2 (wrong results) do not exist outside -DABC_DIAG builds
+    finally:
+        kernels.debug_set("sweep4", before)
+        kernels.debug_set("flags", 0)
+    from vllm_amd import _lib
+    with pytest.raises(_lib.AbcError):
+        kernels.debug_set("no_such_knob", 1)
+
+
+def test_no_per_process_launch_state_in_the_library():
+    """Boundary hygiene: kernel attributes are set per launch for the current device, not cached in a
+    process-wide flag; the environment is read in one place (the tuning block's constructor)."""
+    csrc = os.path.join(ROOT, "vllm_amd", "csrc")
+    text = ""
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".inc", ".h")):
+            text += open(os.path.join(csrc, fn)).read()
+    assert not re.search(r"static\s+bool\s+\w*attr\w*", text)
+    assert len(re.findall(r"getenv\(", text)) == 3 and text.count("SweepTuning()") == 1

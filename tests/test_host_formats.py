@@ -94,7 +94,8 @@ def test_driver_resume_bookkeeping(tmp_path, monkeypatch):
 
     monkeypatch.setattr(mining, "upload", lambda x, compute, rows=None, **kw: _CpuEmb(x[rows[0]:rows[1]]))
     monkeypatch.setattr(mining.search, "Embeddings", lambda x, compute, dev=None: _CpuEmb(x))
-    monkeypatch.setattr(mining.search, "mine_negatives", fake_mine)
+    monkeypatch.setattr(mining.parallel.ShardedCorpus, "mine_negatives",
+                        lambda self, qb, k, ratio=0.95, offset=0, **kw: fake_mine(qb, self.shard, k, ratio, offset))
 
     class Crash(Exception):
         pass

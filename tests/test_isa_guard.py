@@ -12,19 +12,28 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "vllm_amd", "csrc", "topk_sweep.hip")
+CSRC = os.path.join(ROOT, "vllm_amd", "csrc")
+SRCS = [os.path.join(CSRC, f"sweep_inst_{n}.hip") for n in ("bf16", "i8", "f32")]   # one translation unit per element type
 
 
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
     if shutil.which("hipcc") is None:
         pytest.skip("hipcc not on PATH")
-    out = tmp_path_factory.mktemp("isa") / "topk_sweep.s"
-    subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-value",
-                    "-mllvm", "-pragma-unroll-threshold=200000",      # as vllm_amd/csrc/Makefile
-                    "-S", "--cuda-device-only", SRC, "-o", str(out)], check=True, cwd=os.path.dirname(SRC),
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return out.read_text()
+    tmp = tmp_path_factory.mktemp("isa")
+    procs = []
+    for src in SRCS:                                                   # the three compile side by side
+        out = tmp / (os.path.basename(src) + ".s")
+        procs.append((out, subprocess.Popen(
+            ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-value",
+             "-mllvm", "-pragma-unroll-threshold=200000",              # as vllm_amd/csrc/Makefile
+             "-S", "--cuda-device-only", src, "-o", str(out)], cwd=CSRC,
+            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    text = ""
+    for out, pr in procs:
+        assert pr.wait() == 0, out
+        text += out.read_text()
+    return text
 
 
 def _kernel(isa_text, dt, count, four_wave=False):

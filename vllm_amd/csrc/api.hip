@@ -90,9 +90,13 @@ extern "C" int abc_topk_i8(const void* q, const float* qs, int64_t nq, const voi
     return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 
-extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
-                              int64_t* out_idx, void* stream) {
+extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, int64_t idx_limit,
+                              float* out_val, int64_t* out_idx, void* stream) {
     if (parts < 1 || nq < 0 || k < 1 || k > ABC_MAX_K) return fail(ABC_E_INVALID, "bad merge shape parts=%d nq=%lld k=%d", parts, (long long)nq, k);
+    // the merge packs (score, index) into one 64-bit key with a 32-bit index field (0xFFFFFFFF - index, key 0 = hole)
+    if (idx_limit < 0 || idx_limit > 0xFFFFFFFFll)
+        return fail(ABC_E_INVALID, "merge: idx_limit=%lld: indices must lie in [0, 2^32-1) (32-bit index field of the packed keys)",
+                    (long long)idx_limit);
     if (nq == 0) return ABC_OK;
     if (!vals || !idx || !out_val || !out_idx) return fail(ABC_E_INVALID, "null pointer");
     hipError_t he = hipSuccess;
@@ -101,8 +105,16 @@ extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, 
     return rc;
 }
 
+// Diagnostics hook (tests, timing scripts): "sweep4" -1 / 0 / 1, "flags", "plan_qb"; see topk_sweep.h.
+extern "C" int abc_debug_set(const char* name, int64_t value) {
+    const int rc = sweep_debug_set(name, (long)value);
+    return rc == ABC_OK ? ABC_OK : fail(ABC_E_INVALID, "abc_debug_set: unknown knob");
+}
+extern "C" int64_t abc_debug_get(const char* name) { return (int64_t)sweep_debug_get(name); }
+
 // ------------------------------------------------------------------------------------------------
-// rowdot: one wave per row, 16-byte loads, fp32 accumulate, fixed reduction order.
+// rowdot for shapes the sweep does not take (row bytes not a multiple of 128): one wave per row, 16-byte loads,
+// fp32 accumulate, fixed reduction order.  Every other shape goes through rowdot_run (the sweep's MFMA arithmetic).
 template <int DT>
 __global__ __launch_bounds__(256) void rowdot_kernel(const char* __restrict__ q, const char* __restrict__ c,
                                                      const float* __restrict__ qs, const float* __restrict__ cs,
@@ -155,6 +167,12 @@ static int rowdot_entry(int dt, const void* q, const float* qs, const void* c, c
     const int rowbytes = d * elem_size(dt);
     const unsigned grid = (unsigned)((n + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
+    if (rowbytes % 128 == 0) {
+        // every shape the sweep accepts: the sweep's own MFMA arithmetic, bit-identical to the tile's score (i, i)
+        hipError_t he = hipSuccess;
+        const int rc = rowdot_run(dt, q, qs, c, cs, n, d, out, st, &he);
+        return rc == ABC_E_HIP ? abc_fail_hip(he, "rowdot launch") : rc;
+    }
     if (dt == ABC_DT_BF16) hipLaunchKernelGGL(rowdot_kernel<ABC_DT_BF16>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
     else if (dt == ABC_DT_F32) hipLaunchKernelGGL(rowdot_kernel<ABC_DT_F32>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
     else hipLaunchKernelGGL(rowdot_kernel<ABC_DT_I8>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);

@@ -23,13 +23,15 @@ struct SweepParams {
     const float* c_scale;   // int8 only
     const float* rank_ref;  // COUNT only
     int64_t rank_excl;      // COUNT only: column (query row + rank_excl) is not counted
-    int debug_flags;        // ABC_DEBUG_FLAGS (timing experiments only; 0 in production; results are WRONG for 1, 2):
+    int debug_flags;        // ABC_DEBUG_FLAGS at load time / abc_debug_set("flags") (timing experiments only; 0 in production;
+                            // 1 and 2 make results WRONG and exist only in -DABC_DIAG builds):
                             //   1      contraction only, no epilogue       2      quick reject only, nothing appended
                             //   8      never refresh the shared bounds     16     debug counters + cycle stamps to stderr
                             //   bits 8-9   refresh spacing 5/4 (0), 9/8, 3/2, 2
                             //   bits 12-13 XCDs that share a group of query blocks: 2 (0, default), 1, 4, 8
                             //   16384  (-DABC_PHASE_STAMPS build only) no staging: the LDS-read + MFMA ceiling
-                            // ABC_PLAN_QB=<n> overrides the query blocks per launch; ABC_LIB picks another .so (A/B runs)
+                            // ABC_PLAN_QB=<n> / abc_debug_set("plan_qb") overrides the query blocks per launch; ABC_LIB picks
+                            // another .so (A/B runs)
     int n_lists;            // 2 * n_splits candidate lists per query
     int pub_m;              // ceil(k / n_lists): rank each list publishes
     float* pub;             // [nq_pad][n_lists] published bounds (start at -inf)
@@ -51,5 +53,12 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
               int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
               hipError_t* herr);
+hipError_t launch_sweep_bf16(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
+hipError_t launch_sweep_i8(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
+hipError_t launch_sweep_f32(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
+int rowdot_run(int dt, const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d, float* out,
+               hipStream_t st, hipError_t* herr);
+int sweep_debug_set(const char* name, long value);
+long sweep_debug_get(const char* name);
 int merge_lists_run(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,
                     int64_t* out_idx, hipStream_t st, hipError_t* herr);

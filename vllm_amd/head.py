@@ -37,13 +37,14 @@ def get_mean_token_embed(input_ids: torch.Tensor, hidden_state: torch.Tensor, pa
     ids = input_ids.to(torch.int64).contiguous()
     im = None if instruction_mask is None else instruction_mask.to(torch.float32).contiguous()
     out = torch.empty((B, H), dtype=torch.float32, device=hs.device)
-    st = kernels._stream(hs)
-    if hs.dtype == torch.bfloat16:
-        rc = lib.abc_mean_pool_bf16(hs.data_ptr(), ids.data_ptr(), int(padding_token_id), kernels._ptr(im), B, S, H,
-                                    0 if keep_fp32 else 1, out.data_ptr(), st)
-    else:
-        rc = lib.abc_mean_pool_f32(hs.data_ptr(), ids.data_ptr(), int(padding_token_id), kernels._ptr(im), B, S, H,
-                                   out.data_ptr(), st)
+    with kernels._on(hs):
+        st = kernels._stream(hs)
+        if hs.dtype == torch.bfloat16:
+            rc = lib.abc_mean_pool_bf16(hs.data_ptr(), ids.data_ptr(), int(padding_token_id), kernels._ptr(im), B, S, H,
+                                        0 if keep_fp32 else 1, out.data_ptr(), st)
+        else:
+            rc = lib.abc_mean_pool_f32(hs.data_ptr(), ids.data_ptr(), int(padding_token_id), kernels._ptr(im), B, S, H,
+                                       out.data_ptr(), st)
     _lib.check(rc, "abc_mean_pool")
     return out if (keep_fp32 or hs.dtype == torch.float32) else out.to(torch.bfloat16)
 
@@ -99,10 +100,11 @@ def _head(mlp: MLP, x: torch.Tensor, normalize: bool, want_bf16: bool = False, w
     need = lib.abc_embed_head_workspace_bytes(B, H, Hd)
     if need == 0:
         raise _lib.AbcError(f"embed head: unsupported sizes H={H}, hidden={Hd} (multiples of 8)")
-    ws = kernels.workspace(need, x.device)
-    rc = lib.abc_embed_head_f32(x.data_ptr(), w1.data_ptr(), kernels._ptr(b1), w2.data_ptr(), kernels._ptr(b2), B, H, Hd,
-                                1 if normalize else 0, out.data_ptr(), kernels._ptr(o16), kernels._ptr(o8),
-                                kernels._ptr(sc), ws.data_ptr(), ws.numel(), kernels._stream(x))
+    with kernels._on(x):
+        ws = kernels.workspace(need, x.device)
+        rc = lib.abc_embed_head_f32(x.data_ptr(), w1.data_ptr(), kernels._ptr(b1), w2.data_ptr(), kernels._ptr(b2), B, H, Hd,
+                                    1 if normalize else 0, out.data_ptr(), kernels._ptr(o16), kernels._ptr(o8),
+                                    kernels._ptr(sc), ws.data_ptr(), ws.numel(), kernels._stream(x))
     _lib.check(rc, "abc_embed_head_f32")
     return out, o16, o8, sc
 

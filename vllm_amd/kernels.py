@@ -10,10 +10,18 @@ from . import _lib
 
 _DT = {torch.bfloat16: _lib.DT_BF16, torch.int8: _lib.DT_I8, torch.float32: _lib.DT_F32}
 _workspaces = {}
+MAX_INDEX = 0xFFFFFFFF          # packed keys carry a 32-bit index field: global row indices must be below this
 
 
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _on(t: torch.Tensor):
+    """Context that makes t's device the current HIP device for the duration of a library call: the C ABI
+    enqueues on the stream it is handed and sets per-device kernel attributes for the CURRENT device, so a
+    tensor on cuda:1 must not be launched while cuda:0 is current."""
+    return torch.cuda.device(t.device)
 
 
 def _need_gpu(*ts: torch.Tensor) -> None:
@@ -27,8 +35,12 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (caller-side allocation, as the ABI requires)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, stream) (caller-side allocation, as the ABI requires).  Work enqueued on
+    one stream runs in order, so calls that share a stream may share the candidate lists; two streams (or two
+    threads, each on its own stream) get two buffers.  Two threads launching on the SAME stream still race on the
+    host side of this cache: give each thread its own stream."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, index, torch.cuda.current_stream(torch.device("cuda", index)).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = None
@@ -64,23 +76,26 @@ def topk(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.T
         rank_ref = rank_ref.to(torch.float32).contiguous()
         assert rank_ref.numel() == nq
         out_rank = torch.empty((nq,), dtype=torch.int64, device=q.device)
+    if c.device != q.device:
+        raise _lib.AbcError(f"query on {q.device} but corpus on {c.device}")
     need = lib.abc_topk_workspace_bytes(nq, nc, d, k, dt)
     if need == 0:
         _lib.check(-1, "abc_topk_workspace_bytes")
-    ws = workspace(need, q.device)
-    st = _stream(q)
     self_off = _lib.NO_SELF if rank_self_offset is None else int(rank_self_offset)
-    if dt == _lib.DT_I8:
-        if q_scale is None or c_scale is None:
-            raise _lib.AbcError("int8 search needs q_scale and c_scale")
-        q_scale, c_scale = q_scale.to(torch.float32).contiguous(), c_scale.to(torch.float32).contiguous()
-        rc = lib.abc_topk_i8(q.data_ptr(), q_scale.data_ptr(), nq, c.data_ptr(), c_scale.data_ptr(), nc, d, k,
-                             _ptr(upper_bound), idx_offset, out_val.data_ptr(), out_idx.data_ptr(),
-                             _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
-    else:
-        fn = lib.abc_topk_bf16 if dt == _lib.DT_BF16 else lib.abc_topk_f32
-        rc = fn(q.data_ptr(), nq, c.data_ptr(), nc, d, k, _ptr(upper_bound), idx_offset, out_val.data_ptr(),
-                out_idx.data_ptr(), _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
+    with _on(q):
+        ws = workspace(need, q.device)
+        st = _stream(q)
+        if dt == _lib.DT_I8:
+            if q_scale is None or c_scale is None:
+                raise _lib.AbcError("int8 search needs q_scale and c_scale")
+            q_scale, c_scale = q_scale.to(torch.float32).contiguous(), c_scale.to(torch.float32).contiguous()
+            rc = lib.abc_topk_i8(q.data_ptr(), q_scale.data_ptr(), nq, c.data_ptr(), c_scale.data_ptr(), nc, d, k,
+                                 _ptr(upper_bound), idx_offset, out_val.data_ptr(), out_idx.data_ptr(),
+                                 _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
+        else:
+            fn = lib.abc_topk_bf16 if dt == _lib.DT_BF16 else lib.abc_topk_f32
+            rc = fn(q.data_ptr(), nq, c.data_ptr(), nc, d, k, _ptr(upper_bound), idx_offset, out_val.data_ptr(),
+                    out_idx.data_ptr(), _ptr(rank_ref), self_off, _ptr(out_rank), ws.data_ptr(), ws.numel(), st)
     _lib.check(rc, "abc_topk")
     return out_val, out_idx, out_rank
 
@@ -94,28 +109,31 @@ def rowdot(q: torch.Tensor, c: torch.Tensor, q_scale=None, c_scale=None) -> torc
     q, c = q.contiguous(), c.contiguous()
     n, d = q.shape
     out = torch.empty((n,), dtype=torch.float32, device=q.device)
-    st = _stream(q)
-    if q.dtype == torch.int8:
-        rc = lib.abc_rowdot_i8(q.data_ptr(), q_scale.contiguous().data_ptr(), c.data_ptr(),
-                               c_scale.contiguous().data_ptr(), n, d, out.data_ptr(), st)
-    elif q.dtype == torch.bfloat16:
-        rc = lib.abc_rowdot_bf16(q.data_ptr(), c.data_ptr(), n, d, out.data_ptr(), st)
-    else:
-        rc = lib.abc_rowdot_f32(q.data_ptr(), c.data_ptr(), n, d, out.data_ptr(), st)
+    with _on(q):
+        st = _stream(q)
+        if q.dtype == torch.int8:
+            rc = lib.abc_rowdot_i8(q.data_ptr(), q_scale.contiguous().data_ptr(), c.data_ptr(),
+                                   c_scale.contiguous().data_ptr(), n, d, out.data_ptr(), st)
+        elif q.dtype == torch.bfloat16:
+            rc = lib.abc_rowdot_bf16(q.data_ptr(), c.data_ptr(), n, d, out.data_ptr(), st)
+        else:
+            rc = lib.abc_rowdot_f32(q.data_ptr(), c.data_ptr(), n, d, out.data_ptr(), st)
     _lib.check(rc, "abc_rowdot")
     return out
 
 
-def merge_topk(vals: torch.Tensor, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Merge [parts, nq, k] sorted lists (global indices, -1 = missing) into [nq, k]."""
+def merge_topk(vals: torch.Tensor, idx: torch.Tensor, idx_limit: int = MAX_INDEX) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge [parts, nq, k] sorted lists (global indices, -1 = missing) into [nq, k].  `idx_limit` is the exclusive
+    upper bound of the indices (the corpus' total row count): beyond 2^32-1 the library refuses instead of wrapping."""
     _need_gpu(vals, idx)
     lib = _lib.load()
     vals, idx = vals.to(torch.float32).contiguous(), idx.to(torch.int64).contiguous()
     parts, nq, k = vals.shape
     out_val = torch.empty((nq, k), dtype=torch.float32, device=vals.device)
     out_idx = torch.empty((nq, k), dtype=torch.int64, device=vals.device)
-    rc = lib.abc_topk_merge(vals.data_ptr(), idx.data_ptr(), parts, nq, k, out_val.data_ptr(), out_idx.data_ptr(),
-                            _stream(vals))
+    with _on(vals):
+        rc = lib.abc_topk_merge(vals.data_ptr(), idx.data_ptr(), parts, nq, k, int(idx_limit), out_val.data_ptr(),
+                                out_idx.data_ptr(), _stream(vals))
     _lib.check(rc, "abc_topk_merge")
     return out_val, out_idx
 
@@ -128,7 +146,9 @@ def quantize_i8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     n, d = x.shape
     q = torch.empty((n, d), dtype=torch.int8, device=x.device)
     s = torch.empty((n,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.abc_quantize_i8(x.data_ptr(), n, d, q.data_ptr(), s.data_ptr(), _stream(x)), "abc_quantize_i8")
+    with _on(x):
+        rc = lib.abc_quantize_i8(x.data_ptr(), n, d, q.data_ptr(), s.data_ptr(), _stream(x))
+    _lib.check(rc, "abc_quantize_i8")
     return q, s
 
 
@@ -138,5 +158,16 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = x.to(torch.float32).contiguous()
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.abc_cast_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)), "abc_cast_bf16")
+    with _on(x):
+        rc = lib.abc_cast_bf16(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x))
+    _lib.check(rc, "abc_cast_bf16")
     return out
+
+
+def debug_set(name: str, value: int) -> None:
+    """Diagnostics hook of the library (tests, timing scripts): "sweep4" -1/0/1, "flags", "plan_qb"."""
+    _lib.check(_lib.load().abc_debug_set(name.encode(), int(value)), "abc_debug_set")
+
+
+def debug_get(name: str) -> int:
+    return int(_lib.load().abc_debug_get(name.encode()))

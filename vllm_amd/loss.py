@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .kernels import _stream
+from .kernels import _on, _stream
 
 
 class Temperature(torch.nn.Module):
@@ -47,8 +47,9 @@ class _InfoNCE(torch.autograd.Function):
         lse = torch.empty((B,), dtype=torch.float32, device=q.device)
         amax = torch.empty((B,), dtype=torch.int32, device=q.device)
         t = temp.detach().to(device=q.device, dtype=torch.float32).reshape(1).contiguous()   # stays on the device
-        rc = lib.abc_infonce_fwd(q.data_ptr(), p.data_ptr(), t.data_ptr(), float(eps), B, C, d, loss.data_ptr(),
-                                 lse.data_ptr(), amax.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q))
+        with _on(q):
+            rc = lib.abc_infonce_fwd(q.data_ptr(), p.data_ptr(), t.data_ptr(), float(eps), B, C, d, loss.data_ptr(),
+                                     lse.data_ptr(), amax.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q))
         _lib.check(rc, "abc_infonce_fwd")
         ctx.save_for_backward(q, p, lse, ws, t)
         ctx.meta = (float(eps), B, C, d, int(local_rows), temp.dtype)
@@ -67,10 +68,11 @@ class _InfoNCE(torch.autograd.Function):
         if need_p:
             dp = torch.zeros_like(p) if local_rows < C else torch.empty_like(p)
         dt = torch.empty((), dtype=torch.float32, device=q.device) if need_t else None
-        rc = lib.abc_infonce_bwd(q.data_ptr(), p.data_ptr(), lse.data_ptr(), t.data_ptr(), eps, go.data_ptr(), B, C, d,
-                                 local_rows if need_p else 0, None if dq is None else dq.data_ptr(),
-                                 None if dp is None else dp.data_ptr(), None if dt is None else dt.data_ptr(),
-                                 ws.data_ptr(), ws.numel(), _stream(q))
+        with _on(q):
+            rc = lib.abc_infonce_bwd(q.data_ptr(), p.data_ptr(), lse.data_ptr(), t.data_ptr(), eps, go.data_ptr(), B, C, d,
+                                     local_rows if need_p else 0, None if dq is None else dq.data_ptr(),
+                                     None if dp is None else dp.data_ptr(), None if dt is None else dt.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream(q))
         _lib.check(rc, "abc_infonce_bwd")
         return dq, dp, (None if dt is None else dt.to(tdtype)), None, None
 
@@ -98,6 +100,19 @@ def compute_contrastive_loss(q_embeds, p_embeds, temperature, label_smoothing=0.
     return _loss_and_acc(q_embeds, p_embeds, temperature, label_smoothing, p_embeds.size(0))
 
 
+def _all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """[n, ...] -> [world * n, ...], ONE collective.  RCCL (backend "nccl") takes the device tensor as it is; under
+    a gloo group (CPU-side tests, one-GPU rehearsals) device tensors cross in host memory, because gloo's
+    collectives on device tensors do not complete on this stack (vllm_amd/parallel.py)."""
+    world = dist.get_world_size()
+    x = x.detach().contiguous()
+    staged = x.is_cuda and dist.get_backend() == "gloo"
+    src = x.cpu() if staged else x
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out.to(x.device) if staged else out
+
+
 def gathered_candidates(c_emb: torch.Tensor):
     """all_gather of the candidate block, local block swapped into slot 0 (model/abc_util.py:15-27).
     Returns (c_global [W*n, D] -- rows [0, n) are the local, grad-carrying block -- and n)."""
@@ -105,8 +120,7 @@ def gathered_candidates(c_emb: torch.Tensor):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return c_emb, n
     world, rank = dist.get_world_size(), dist.get_rank()
-    gathered = torch.empty((world * n,) + tuple(c_emb.shape[1:]), dtype=c_emb.dtype, device=c_emb.device)
-    dist.all_gather_into_tensor(gathered, c_emb.detach().contiguous())      # one collective, no gradient
+    gathered = _all_gather_rows(c_emb)                                       # one collective, no gradient
     gathered = gathered.view((world,) + tuple(c_emb.shape))
     blocks = [c_emb if r == rank else gathered[r] for r in _slot_order(world, rank)]
     return torch.cat(blocks, dim=0), n
@@ -128,10 +142,7 @@ class _AllGatherWithGrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c_emb):
         world, rank = dist.get_world_size(), dist.get_rank()
-        n = c_emb.size(0)
-        gathered = torch.empty((world * n,) + tuple(c_emb.shape[1:]), dtype=c_emb.dtype, device=c_emb.device)
-        dist.all_gather_into_tensor(gathered, c_emb.detach().contiguous())
-        gathered = gathered.view((world,) + tuple(c_emb.shape))
+        gathered = _all_gather_rows(c_emb).view((world,) + tuple(c_emb.shape))
         ctx.order = _slot_order(world, rank)
         ctx.shape = tuple(c_emb.shape)
         return torch.cat([gathered[r] for r in ctx.order], dim=0)
@@ -147,8 +158,10 @@ class _AllGatherWithGrad(torch.autograd.Function):
             out = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
             dist.reduce_scatter_tensor(out, canon.view((world * ctx.shape[0],) + ctx.shape[1:]), op=dist.ReduceOp.SUM)
             return out
-        dist.all_reduce(canon, op=dist.ReduceOp.SUM)        # gloo (CPU tests) has no reduce-scatter
-        return canon[rank].clone()
+        # gloo (CPU tests, one-GPU rehearsals) has no reduce-scatter; device tensors cross in host memory
+        h = canon.cpu() if canon.is_cuda else canon
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        return h[rank].to(g.device).clone()
 
 
 def compute_gathered_loss(q_emb, c_emb, temperature, label_smoothing=0.0, differentiable_gather=False):

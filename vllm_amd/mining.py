@@ -221,10 +221,8 @@ def create_negative_index(negative_path: str, top: int = 100, ratio: float = 0.9
         corpus = parallel.ShardedCorpus(shard, lo, n)
         for s, m in todo:
             qb = search.Embeddings(q_cpu[s:s + m], compute, shard.data.device)
-            if world == 1:
-                idx, _, _ = search.mine_negatives(qb, shard, top_eff, ratio=ratio, offset=s)
-            else:
-                idx, _, _ = corpus.mine_negatives(qb, top_eff, ratio=ratio, offset=s)
+            # one code path at every world size (world 1: no collective, the local sweep is the result)
+            idx, _, _ = corpus.mine_negatives(qb, top_eff, ratio=ratio, offset=s)
             if rank == 0:
                 arr = idx.to(torch.int64).cpu().numpy()
                 tmp = os.path.join(parts_dir, _part_name(s) + ".tmp")

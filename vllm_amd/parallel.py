@@ -16,6 +16,9 @@ import torch
 import torch.distributed as dist
 
 
+MAX_ROWS = 0xFFFFFFFF      # exclusive: index 0xFFFFFFFF would collide with the reserved empty key
+
+
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     """Rows [lo, hi) of rank `rank`: contiguous, sizes differ by at most one."""
     base, rem = divmod(n_rows, world)
@@ -29,7 +32,7 @@ class Backend:
     CPU-only tests of the exchange logic bind a checker instead (tests/ only)."""
     topk: Callable          # (q, c_shard, k, upper_bound, idx_offset) -> (vals [nq,k], idx [nq,k] global, -1 = hole)
     rowdot: Callable        # (q_rows, c_rows) -> [n] f32
-    merge: Callable         # (vals [P,nq,k], idx [P,nq,k]) -> (vals [nq,k], idx [nq,k])
+    merge: Callable         # (vals [P,nq,k], idx [P,nq,k], idx_limit) -> (vals [nq,k], idx [nq,k])
 
 
 def hip_backend() -> Backend:
@@ -49,6 +52,9 @@ class ShardedCorpus:
     """This rank's rows [lo, hi) of an n_total-row corpus."""
 
     def __init__(self, shard, lo: int, n_total: int, group=None, backend: Optional[Backend] = None):
+        if n_total >= MAX_ROWS:
+            raise ValueError(f"n_total={n_total}: global row indices travel in the 32-bit index field of the packed "
+                             f"(score, index) keys; a sharded corpus holds at most {MAX_ROWS - 1} rows")
         self.shard, self.lo, self.n_total = shard, lo, n_total
         self.hi = lo + shard.shape[0]
         self.group = group
@@ -121,16 +127,25 @@ class ShardedCorpus:
             wv.wait()
             wi.wait()
             gv, gi = gv.to(dev), gi.to(dev)
-            mv, mi = self.backend.merge(gv.view(self.world, v.shape[0], k), gi.view(self.world, i.shape[0], k))
+            mv, mi = self.backend.merge(gv.view(self.world, v.shape[0], k), gi.view(self.world, i.shape[0], k), self.n_total)
             outs_v.append(mv)
             outs_i.append(mi)
         if len(outs_v) == 1:
             return outs_v[0], outs_i[0]
         return torch.cat(outs_v, dim=0), torch.cat(outs_i, dim=0)
 
-    def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0):
+    def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0, fill_masked_tail: bool = True):
         """Sharded form of pretrain/create_negative_index.py:45-52 for queries whose positives are
-        corpus rows offset .. offset+n-1.  Returns (idx, vals, s_pos)."""
+        corpus rows offset .. offset+n-1.  Returns (idx, vals, s_pos), identical on every rank and identical
+        to search.mine_negatives on the unsharded corpus: rows with fewer than k survivors get their tail filled
+        with the masked columns by the same helper (a second, unbounded sharded search of those rows; the merged
+        lists are replicated, so every rank sees the same rows and takes part in the same collectives)."""
+        from .search import fill_masked_tail_rows
         s_pos = self.positive_scores(q, offset)
-        v, i = self.topk(q, k, upper_bound=s_pos * ratio)
+        ub = s_pos * ratio
+        v, i = self.topk(q, k, upper_bound=ub)
+        if fill_masked_tail and self.world > 1:
+            fill_masked_tail_rows(i, ub, lambda rows: self.topk(q.take(rows), k))
+        elif fill_masked_tail:
+            fill_masked_tail_rows(i, ub, lambda rows: self.backend.topk(q.take(rows), self.shard, k, None, self.lo))
         return i, v, s_pos

@@ -133,15 +133,26 @@ def mine_negatives(q: Embeddings, c: Embeddings, k: int = 100, ratio: float = 0.
     ub = s_pos * ratio                                   # fp32 multiply, as scores[idx]*.95
     vals, idx, _ = topk(q, c, k, upper_bound=ub)
     if fill_masked_tail:
-        holes = (idx < 0).any(dim=1).nonzero().flatten()
-        if holes.numel():
-            v2, i2, _ = topk(q.take(holes), c, k)
-            for r, row in enumerate(holes.tolist()):
-                masked = i2[r][(v2[r] > ub[row]) & (i2[r] >= 0)]
-                n_ok = int((idx[row] >= 0).sum())
-                take = min(k - n_ok, masked.numel())
-                idx[row, n_ok:n_ok + take] = masked[:take]
+        fill_masked_tail_rows(idx, ub, lambda rows: topk(q.take(rows), c, k)[:2])
     return idx, vals, s_pos
+
+
+def fill_masked_tail_rows(idx: torch.Tensor, ub: torch.Tensor, unbounded_topk) -> None:
+    """Rows of `idx` with fewer than k survivors (-1 holes) get the masked columns appended, best first, as the
+    reference's argsort()[:top] does (create_negative_index.py:50-51 always yields `top` entries; the consumer
+    indexes up to 5*negatives-1, conceptual_captions.py:152-156).  `unbounded_topk(rows) -> (vals, idx)` is a
+    second search of those rows without the bound; the single-GPU and the sharded driver both come through here,
+    so a mining run writes the same lists at every world size."""
+    k = idx.shape[1]
+    holes = (idx < 0).any(dim=1).nonzero().flatten()
+    if not holes.numel():
+        return
+    v2, i2 = unbounded_topk(holes)
+    for r, row in enumerate(holes.tolist()):
+        masked = i2[r][(v2[r] > ub[row]) & (i2[r] >= 0)]
+        n_ok = int((idx[row] >= 0).sum())
+        take = min(k - n_ok, masked.numel())
+        idx[row, n_ok:n_ok + take] = masked[:take]
 
 
 def negatives_for_sample(idx: int, negative_dict: dict, q: torch.Tensor, c, top: int = 100, compute: str = "f32"):
