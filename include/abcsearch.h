@@ -141,6 +141,20 @@ int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps
                     float* out_loss, float* out_lse, int32_t* out_argmax,
                     void* workspace, size_t workspace_bytes, void* stream);
 /*
+ * The forward for callers that cannot allocate.  No counterpart in the reference; it exists for callers that must
+ * not call hipMalloc or hand over a workspace: code under HIP graph capture, tight evaluation loops, harnesses that
+ * forbid allocation.  Same arithmetic and results as abc_infonce_fwd, bit for bit; the scratch abc_infonce_fwd takes
+ * as `workspace` lives in a 16 MiB device array inside the library (one copy per GPU, held until the process ends).
+ * Shapes whose abc_infonce_workspace_bytes exceeds abc_infonce_noalloc_max_bytes() are refused with ABC_E_WORKSPACE
+ * (B=128 x C=8192, the 8-GPU form of BASELINE configs[3], needs 8.3 MiB).  Calls no hipMalloc / hipFree.
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ * There is no backward for it: the logits stay in the library's array only until the next call.
+ */
+size_t abc_infonce_noalloc_max_bytes(void);
+int abc_infonce_fwd_noalloc(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
+                            float* out_loss, float* out_lse, int32_t* out_argmax, void* stream);
+
+/*
  * InfoNCE backward (closed form of the autograd of model/abc_util.py:47-51):
  *   g = (softmax(z) - [(1-eps)1{j=i} + eps/C]) * grad_out / B
  *   dq = (g/temp) p ; dp_local = ((g/temp)^T q)[:local_rows] ; d_temp = -sum(g*s)/temp^2

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/abcsearch.h"
 #include "nt_gemm.h"
+#include <atomic>
 
 int abc_fail_hip(hipError_t e, const char* where);
 int abc_fail_invalid(const char* msg);
@@ -557,6 +558,56 @@ extern "C" int abc_infonce_fwd(const float* q, const float* p, const float* temp
     nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, w, L, st);
     e = hipGetLastError();
     return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "infonce_fwd launch");
+}
+
+// ------------------------------------------------------------------------------------------------
+// The forward for callers that must not allocate (HIP graph capture, tight evaluation loops, harnesses that forbid
+// hipMalloc): same kernel, same layout, but the scratch (logits, split-K slabs, row statistics, arrival counters)
+// lives in a file-scope device array instead of a caller-provided workspace.  Each GPU the library runs on holds its
+// own copy of the array at its own address until the process ends; the host-side name `scratch` is only a handle for
+// hipGetSymbolAddress, never a device address.
+#define NCE_SCRATCH_BYTES (16u << 20)
+#define NCE_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[NCE_SCRATCH_BYTES];
+static std::atomic<void*> g_scratch_ptr[NCE_MAX_DEVICES];
+
+static int nce_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc hipGetDevice");
+    if (dev < 0 || dev >= NCE_MAX_DEVICES) return abc_fail_invalid("infonce_fwd_noalloc: device index out of range");
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {                                   // first call on this device, with this device current
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return abc_fail_hip(e, "infonce_fwd_noalloc hipGetSymbolAddress(scratch)");
+        g_scratch_ptr[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return ABC_OK;
+}
+
+extern "C" size_t abc_infonce_noalloc_max_bytes(void) { return NCE_SCRATCH_BYTES; }
+
+extern "C" int abc_infonce_fwd_noalloc(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
+                                       float* out_loss, float* out_lse, int32_t* out_argmax, void* stream) {
+    int rc = nce_check(B, C, d);
+    if (rc) return rc;
+    if (!q || !p || !temp || !out_loss || !out_lse || !out_argmax) return abc_fail_invalid("infonce_fwd_noalloc: null pointer");
+    if (((uintptr_t)q | (uintptr_t)p) & 15) return abc_fail_invalid("infonce_fwd_noalloc: q and p must be 16-byte aligned");
+    const NceLayout L = nce_layout(B, C, d);
+    if (L.total > NCE_SCRATCH_BYTES) return abc_fail_ws(L.total, NCE_SCRATCH_BYTES);   // "workspace too small: need N bytes, have 16 MiB"
+    void* sp = nullptr;
+    rc = nce_scratch(&sp);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)sp;
+    // the array keeps the last call's contents: the counters must start at zero (a completed call leaves them at zero
+    // itself; this covers a call that was abandoned half-way).  Everything else is written before it is read.
+    hipError_t e = hipMemsetAsync(w + L.off_cnt, 0, (size_t)L.n_cnt * 4, st);
+    if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc memset");
+    nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, w, L, st);
+    e = hipGetLastError();
+    return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "infonce_fwd_noalloc launch");
 }
 
 extern "C" int abc_infonce_bwd(const float* q, const float* p, const float* lse, const float* temp, float eps,
