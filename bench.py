@@ -221,13 +221,7 @@ def main():
 
 
 def sweep_kernel_name(rows):
-    """Which sweep kernel libabcsearch takes for a shard of `rows` rows at this bench's 8192 queries per launch
-    (32 query blocks x 8 splits): the rule of use_sweep4() in vllm_amd/csrc/topk_sweep.hip, restated for the label."""
-    tiles = (rows + 255) // 256
-    from vllm_amd import kernels
-    forced = kernels.debug_get("sweep4")                  # -1: by sweep length
-    four = bool(forced) if forced >= 0 else tiles // 8 >= 384
-    return "topk_sweep4_kernel<bf16>" if four else "topk_sweep_kernel<bf16>"
+    return "topk_sweep16_kernel<bf16>"
 
 
 def cpu_baseline(batch, shard, nc, gpu_out, dev):

@@ -132,10 +132,10 @@ void sweep4c_kernel(const char* __restrict__ q, const char* __restrict__ c, int 
                 MFMA16(acc[(LO) + m_ / NB][m_ % NB], a[(LO) + m_ / NB], FB[m_ % NB]);                            \
             }                                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
-            if (i < 8) {                                                                                         \
-                _Pragma("unroll") for (int j = (i * (NR)) / 8; j < ((i + 1) * (NR)) / 8; ++j) { RD(j) }          \
+            if ((DMA) == 2 ? i >= 8 : i < 8) {                                                                   \
+                _Pragma("unroll") for (int j = ((i & 7) * (NR)) / 8; j < (((i & 7) + 1) * (NR)) / 8; ++j) { RD(j) } \
             } else if (DMA) {                                                                                    \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds((HALF) ? rq : rc, LDS_PTR(dst_ + (i - 8) * 1024), 16, voff2[i & 1], so_ + (i - 8) * piece, 0, 0); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds((HALF) ? rq : rc, LDS_PTR(dst_ + (i & 7) * 1024), 16, voff2[i & 1], so_ + (i & 7) * piece, 0, 0); \
             } else if ((HALF) == 2 && (i == PF_AT || i == PF_AT + 1)) {                                          \
                 /* L2 prefetch of the lines this wave stages one phase after the next issue: one lane per 128-byte line */ \
                 if (i == PF_AT) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_sink) : "v"(pf_voff), "s"(rc), "s"(pf_cb + pf_k * ROWB)); \
@@ -175,7 +175,11 @@ void sweep4c_kernel(const char* __restrict__ q, const char* __restrict__ c, int 
                 // H0: k-step 0, first half of the A tiles; reads: the second half of the A tiles, half of k-step 1's B;
                 // query pieces of phase ph+1 -> the other slot
 #ifndef NO_DMA
+#ifdef DMA_FIRST_H0
+                HALF_STEP(b0, 0, MB / 2 + NB / 2, RD_H0, 2, 1);
+#else
                 HALF_STEP(b0, 0, MB / 2 + NB / 2, RD_H0, 1, 1);
+#endif
                 ISSUE_ADVANCE();
 #else
                 HALF_STEP(b0, 0, MB / 2 + NB / 2, RD_H0, 0, 1);

@@ -88,7 +88,7 @@ int abc_topk_i8(const void* q, const float* q_scale, int64_t nq, const void* c, 
  * out[i] = dot(q[i,:], c[i,:]) in fp32, i < n.  Replaces scores[idx] of
  * pretrain/create_negative_index.py:48 and the bmm of visualization/neg_mine.py:32-35.
  * For every shape abc_topk_* accepts (d*sizeof(elem) % 128 == 0) the value is contracted by the same MFMA
- * instruction, fragments and k order as the sweep, i.e. it is BIT-IDENTICAL to the score abc_topk_* sees for
+ * instruction (16 x 16 tiles), fragments and k order as the sweep, i.e. it is BIT-IDENTICAL to the score abc_topk_* sees for
  * column i of query i -- the reference takes scores[idx] out of the same GEMV it masks (:47-49).
  */
 int abc_rowdot_bf16(const void* q, const void* c, int64_t n, int d, float* out, void* stream);
@@ -110,11 +110,10 @@ int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq,
 /*
  * Diagnostics hook for tests and timing scripts (no counterpart in the reference; not for production use: it
  * changes process-wide settings, do not call it while another thread is inside abc_topk_*):
- *   "sweep4"  -1 pick the sweep kernel by sweep length (default), 0 / 1 force the 8-wave / one-wave-per-SIMD kernel
  *   "flags"   SweepParams::debug_flags (cycle stamps, refresh spacing, XCD grouping; result-altering bits are
  *             masked out unless the library was built with -DABC_DIAG)
  *   "plan_qb" query blocks per launch (0 = the library's plan)
- * The same knobs are read from ABC_SWEEP4 / ABC_DEBUG_FLAGS / ABC_PLAN_QB once, when the library is loaded.
+ * The same knobs are read from ABC_DEBUG_FLAGS / ABC_PLAN_QB once, when the library is loaded.
  */
 int abc_debug_set(const char* name, int64_t value);
 int64_t abc_debug_get(const char* name);

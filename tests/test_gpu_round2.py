@@ -54,31 +54,26 @@ def test_compute_topk_file_layout(tmp_path):
 
 @pytest.mark.parametrize("compute,d", [("bf16", 4096), ("f32", 4096), ("i8", 3584), ("bf16", 64)])
 def test_positive_score_is_the_tile_score(compute, d):
-    """s_pos[i] from abc_rowdot_* == the score abc_topk_* holds for (query i, column i), bit for bit, with both
-    sweep kernels: with the bound at exactly s_pos (ratio 1.0) the positive survives and every exact duplicate of it
-    ties with it; nothing scoring above it does."""
-    from vllm_amd import kernels, search
+    """s_pos[i] from abc_rowdot_* == the score abc_topk_* holds for (query i, column i), bit for bit: with the bound
+    at exactly s_pos (ratio 1.0) the positive survives and every exact duplicate of it ties with it; nothing scoring
+    above it does."""
+    from vllm_amd import search
     n = 96
     q, c = oracle.make_clustered(n, n, d, seed=d + len(compute), n_centres=4, q_noise=0.2)
     c[40] = c[7]                                       # an exact duplicate of a positive
     qe = search.Embeddings(q, compute, DEV)
     ce = search.Embeddings(c, compute, DEV)
     s_pos = search.positive_scores(qe, ce)
-    try:
-        for four in (0, 1):
-            kernels.debug_set("sweep4", four)
-            v, i, _ = search.topk(qe, ce, n)           # k = nc: every column's score comes back
-            tile = torch.gather(v, 1, (i == torch.arange(n, device=DEV)[:, None]).float().argmax(1, keepdim=True)).squeeze(1)
-            assert torch.equal(tile, s_pos), float((tile - s_pos).abs().max())
-            idx, vals, sp = search.mine_negatives(qe, ce, 16, ratio=1.0, fill_masked_tail=False)
-            assert torch.equal(sp, s_pos)
-            assert bool((vals[:, 0] == s_pos).all())   # the best survivor scores exactly s_pos ...
-            assert bool((vals <= s_pos[:, None]).all())
-            first = idx[:, 0].cpu()
-            assert bool(((first == torch.arange(n)) | ((torch.arange(n) == 40) & (first == 7))).all())   # ... and is the positive
-            assert idx[7, :2].tolist() == [7, 40] and idx[40, :2].tolist() == [7, 40]                  # duplicates tie, index order
-    finally:
-        kernels.debug_set("sweep4", -1)
+    v, i, _ = search.topk(qe, ce, n)                   # k = nc: every column's score comes back
+    tile = torch.gather(v, 1, (i == torch.arange(n, device=DEV)[:, None]).float().argmax(1, keepdim=True)).squeeze(1)
+    assert torch.equal(tile, s_pos), float((tile - s_pos).abs().max())
+    idx, vals, sp = search.mine_negatives(qe, ce, 16, ratio=1.0, fill_masked_tail=False)
+    assert torch.equal(sp, s_pos)
+    assert bool((vals[:, 0] == s_pos).all())           # the best survivor scores exactly s_pos ...
+    assert bool((vals <= s_pos[:, None]).all())
+    first = idx[:, 0].cpu()
+    assert bool(((first == torch.arange(n)) | ((torch.arange(n) == 40) & (first == 7))).all())   # ... and is the positive
+    assert idx[7, :2].tolist() == [7, 40] and idx[40, :2].tolist() == [7, 40]                  # duplicates tie, index order
 
 
 def test_mining_bound_without_slack():

@@ -13,17 +13,6 @@ def _dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["auto", "sweep4"])
-def sweep_kernel(request):
-    """Every test of this file runs twice: with the kernel the library picks by sweep length (the 8-wave one at
-    these sizes) and with the one-wave-per-SIMD kernel forced (abc_debug_set "sweep4"; the environment is only
-    read when the library is loaded)."""
-    from vllm_amd import kernels
-    kernels.debug_set("sweep4", 1 if request.param == "sweep4" else -1)
-    yield request.param
-    kernels.debug_set("sweep4", -1)
-
-
 def _run(q, c, k, **kw):
     from vllm_amd import kernels
     dev = _dev()

@@ -198,17 +198,17 @@ def test_debug_knobs_are_process_state_not_environment(monkeypatch):
     """ABC_* variables are read once, when the library is loaded: changing the environment afterwards does nothing;
     abc_debug_set is the only way to change a knob, and result-altering flag bits are masked in a production build."""
     from vllm_amd import kernels
-    before = kernels.debug_get("sweep4")
-    monkeypatch.setenv("ABC_SWEEP4", "1" if before != 1 else "0")
+    before = kernels.debug_get("plan_qb")
+    monkeypatch.setenv("ABC_PLAN_QB", "16" if before != 16 else "24")
     monkeypatch.setenv("ABC_DEBUG_FLAGS", "3")
-    assert kernels.debug_get("sweep4") == before and kernels.debug_get("flags") & 3 == 0
+    assert kernels.debug_get("plan_qb") == before and kernels.debug_get("flags") & 3 == 0
     try:
-        kernels.debug_set("sweep4", 1)
-        assert kernels.debug_get("sweep4") == 1
-        kernels.debug_set("flags", 1 | 2 | 16)
-        assert kernels.debug_get("flags") == 16            # 1 and 2 (wrong results) do not exist outside -DABC_DIAG builds
+        kernels.debug_set("plan_qb", 16)
+        assert kernels.debug_get("plan_qb") == 16
+        kernels.debug_set("flags", 1 | 2 | 8)
+        assert kernels.debug_get("flags") == 8             # 1 and 2 (wrong results) do not exist outside -DABC_DIAG builds
     finally:
-        kernels.debug_set("sweep4", before)
+        kernels.debug_set("plan_qb", before)
         kernels.debug_set("flags", 0)
     from vllm_amd import _lib
     with pytest.raises(_lib.AbcError):
@@ -224,4 +224,4 @@ def test_no_per_process_launch_state_in_the_library():
         if fn.endswith((".hip", ".inc", ".h")):
             text += open(os.path.join(csrc, fn)).read()
     assert not re.search(r"static\s+bool\s+\w*attr\w*", text)
-    assert len(re.findall(r"getenv\(", text)) == 3 and text.count("SweepTuning()") == 1
+    assert len(re.findall(r"getenv\(", text)) == 2 and text.count("SweepTuning()") == 1

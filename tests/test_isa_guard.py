@@ -1,9 +1,8 @@
-"""Compile-time guard of the sweep kernel's steady-state phase loop (no GPU needed: hipcc cross-compiles).
+"""Compile-time guard of the sweep kernel's phase loop (no GPU needed: hipcc cross-compiles).
 
-hipcc's waitcnt pass once guarded the fragment registers with an `s_waitcnt vmcnt(0)` INSIDE that loop -- a
-drain of the LDS-DMA ring in every phase -- after an unrelated register-allocation change.
-The loop must stay: 12 ds_read_b128, 4 LDS-DMA pieces, one counted vmcnt(8), 16 MFMAs, 2 barriers, no
-spill reloads and no scratch traffic."""
+hipcc's waitcnt pass once guarded the fragment registers with an `s_waitcnt vmcnt(0)` INSIDE such a loop -- a
+drain of the LDS-DMA pipeline in every phase -- after an unrelated register-allocation change, and
+its register allocator unties MFMA accumulators written through the builtin.  The loop must stay what the source says."""
 import os
 import re
 import shutil
@@ -36,63 +35,37 @@ def isa(tmp_path_factory):
     return text
 
 
-def _kernel(isa_text, dt, count, four_wave=False):
-    name = (f"_Z18topk_sweep4_kernelILi{dt}ELb{count}EEv11SweepParams" if four_wave
-            else f"_Z17topk_sweep_kernelILi{dt}ELb{count}EEv11SweepParams")
+def _kernel(isa_text, dt, count):
+    name = f"_Z19topk_sweep16_kernelILi{dt}ELb{count}EEv11SweepParams"
     m = re.search(rf"^{name}:[^\n]*\n(.*?)s_endpgm", isa_text, re.S | re.M)
     assert m, name
     return m.group(1)
 
 
-def _first_inner_loop(body):
-    """The first depth-2 loop of the kernel is the straight-line steady-state phase loop."""
-    lines = body.split("\n")
-    start = next(i for i, l in enumerate(lines) if "This Inner Loop Header" in l)
-    # the loop ends at the first backward conditional branch after its second s_barrier
-    barriers = 0
-    for j in range(start, len(lines)):
-        if re.match(r"\s*s_barrier", lines[j]):
-            barriers += 1
-        if barriers >= 2 and re.match(r"\s*s_cbranch_scc", lines[j]):
-            return lines[start:j + 1]
-    raise AssertionError("loop end not found")
-
-
-@pytest.mark.parametrize("dt,mfma", [(0, "v_mfma_f32_32x32x16_bf16"), (1, "v_mfma_i32_32x32x32_i8"), (2, "v_mfma_f32_32x32x2_f32")])
-def test_steady_state_phase_loop_is_clean(isa, dt, mfma):
-    loop = _first_inner_loop(_kernel(isa, dt, 0))
-    text = "\n".join(loop)
-    assert text.count("ds_read_b128") == 12
-    assert len(re.findall(r"buffer_load_dwordx4 .* lds", text)) == 4
-    assert text.count(mfma) == (16 if dt != 2 else 64)
-    assert len(re.findall(r"^\s*s_barrier", text, re.M)) == 2
-    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", text)
-    assert waits == ["8"], waits                      # the one counted wait; never a drain
-    assert "v_readlane" not in text and "scratch_" not in text and "s_cbranch_vcc" not in text
+@pytest.mark.parametrize("dt,mfma,per_phase", [(0, "v_mfma_f32_16x16x32_bf16", 128), (1, "v_mfma_i32_16x16x64_i8", 128),
+                                               (2, "v_mfma_f32_16x16x4_f32", 512)])
+def test_phase_loop_is_clean(isa, dt, mfma, per_phase):
+    """topk_sweep16_kernel (one wave per SIMD, 16 x 16 MFMA tiles, asm MFMAs tied in place): the phase loop is two basic
+    blocks (H0-H2 with the barrier, then H3).  Per 128-byte phase: 128 products (x4 MFMAs for f32), 40 fragment reads, 16
+    LDS-DMA pieces, ONE vmcnt wait (the explicit vmcnt(0) before the barrier) -- hipcc once added vmcnt waits inside such
+    a loop when the epilogue's loads were not declared complete --, no accumulator shuffling (v_accvgpr_*) inside the
+    loop, no scratch traffic, accumulators in AGPRs."""
+    body = _kernel(isa, dt, 0)
+    assert "scratch_" not in body, "the accumulators (or spills) went to scratch: is the unroll threshold flag set?"
+    blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
+    loop = [b for b in blocks if b.count(mfma) >= 32]
+    assert len(loop) == 2, [b.count(mfma) for b in blocks if mfma in b]
+    text = "".join(loop)
+    assert text.count(mfma) == per_phase
+    assert text.count("ds_read_b128") == 40
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", text)) == 16
+    assert len(re.findall(r"^\s*s_barrier", text, re.M)) == 1
+    assert re.findall(r"s_waitcnt vmcnt\((\d+)\)", text) == ["0"]
+    assert "v_accvgpr" not in text, "hipcc moves accumulators inside the phase loop"
+    assert re.search(mfma + r" a\[", text), "accumulators not in AGPRs"
 
 
 def test_main_variants_do_not_spill_vectors(isa):
     for dt in (0, 1, 2):
         body = _kernel(isa, dt, 0)
         assert "scratch_" not in body, f"dtype {dt}: vector spills in the mining/search variant"
-
-
-@pytest.mark.parametrize("dt,mfma,per_phase", [(0, "v_mfma_f32_32x32x16_bf16", 64), (1, "v_mfma_i32_32x32x32_i8", 64),
-                                               (2, "v_mfma_f32_32x32x2_f32", 256)])
-def test_four_wave_phase_loop_is_clean(isa, dt, mfma, per_phase):
-    """topk_sweep4_kernel (one wave per SIMD): the phase loop is two basic blocks (steps 1-3 with the barrier, then
-    step 0).  Per 128-byte phase: 32 fragment reads, 16 LDS-DMA pieces, ONE vmcnt wait (the explicit vmcnt(0) before
-    the barrier) -- hipcc once added vmcnt(0)/(1) in step 0, a wait for the pieces issued one step earlier, when the
-    epilogue's loads were not declared complete -- no scratch traffic, accumulators in AGPRs."""
-    body = _kernel(isa, dt, 0, four_wave=True)
-    assert "scratch_" not in body, "the accumulators (or spills) went to scratch: is the unroll threshold flag set?"
-    blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
-    loop = [b for b in blocks if mfma in b]
-    assert len(loop) == 2, [b.count(mfma) for b in loop]
-    text = "".join(loop)
-    assert text.count(mfma) == per_phase
-    assert text.count("ds_read_b128") == 32
-    assert len(re.findall(r"buffer_load_dwordx4 .* lds", text)) == 16
-    assert len(re.findall(r"^\s*s_barrier", text, re.M)) == 1
-    assert re.findall(r"s_waitcnt vmcnt\((\d+)\)", text) == ["0"]
-    assert re.search(mfma + r" a\[", text), "accumulators not in AGPRs"

@@ -105,7 +105,7 @@ extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, 
     return rc;
 }
 
-// Diagnostics hook (tests, timing scripts): "sweep4" -1 / 0 / 1, "flags", "plan_qb"; see topk_sweep.h.
+// Diagnostics hook (tests, timing scripts): "flags", "plan_qb"; see topk_sweep.h.
 extern "C" int abc_debug_set(const char* name, int64_t value) {
     const int rc = sweep_debug_set(name, (long)value);
     return rc == ABC_OK ? ABC_OK : fail(ABC_E_INVALID, "abc_debug_set: unknown knob");

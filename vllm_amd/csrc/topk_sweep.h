@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include "../../include/abcsearch.h"
 
-#define CAND_CAP 512   // candidate-list capacity per (list set, query): 4 KiB of 8-byte keys
+#define CAND_CAP 1024  // candidate-list capacity per (split, query): 8 KiB of 8-byte keys
 
 
 struct SweepParams {
@@ -12,7 +12,6 @@ struct SweepParams {
     const char* c;          // [nc, rowbytes] corpus
     int64_t nq, nc;
     int rowbytes;           // d * sizeof(elem), multiple of 128
-    int nk;                 // rowbytes / 64 phases per tile
     int k;
     int n_qblocks;          // ceil(nq / 256) of this launch
     int n_splits;           // corpus splits; grid = n_qblocks * n_splits
@@ -29,15 +28,14 @@ struct SweepParams {
                             //   8      never refresh the shared bounds     16     debug counters + cycle stamps to stderr
                             //   bits 8-9   refresh spacing 5/4 (0), 9/8, 3/2, 2
                             //   bits 12-13 XCDs that share a group of query blocks: 2 (0, default), 1, 4, 8
-                            //   16384  (-DABC_PHASE_STAMPS build only) no staging: the LDS-read + MFMA ceiling
                             // ABC_PLAN_QB=<n> / abc_debug_set("plan_qb") overrides the query blocks per launch; ABC_LIB picks
                             // another .so (A/B runs)
-    int n_lists;            // 2 * n_splits candidate lists per query
+    int n_lists;            // = n_splits: one candidate list per (split, query)
     int pub_m;              // ceil(k / n_lists): rank each list publishes
     float* pub;             // [nq_pad][n_lists] published bounds (start at -inf)
     unsigned long long* dbg; // debug counters
-    uint64_t* cand;         // [2*n_splits][nq_pad][CAND_CAP] packed keys
-    uint32_t* rank_part;    // [2*n_splits][nq_pad]
+    uint64_t* cand;         // [n_splits][nq_pad][CAND_CAP] packed keys
+    uint32_t* rank_part;    // [n_splits][nq_pad]
 };
 
 struct SweepPlan {
@@ -53,9 +51,9 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
               int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
               hipError_t* herr);
-hipError_t launch_sweep_bf16(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
-hipError_t launch_sweep_i8(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
-hipError_t launch_sweep_f32(bool count, bool four, const SweepParams& p, int grid, hipStream_t st);
+hipError_t launch_sweep_bf16(bool count, const SweepParams& p, int grid, hipStream_t st);
+hipError_t launch_sweep_i8(bool count, const SweepParams& p, int grid, hipStream_t st);
+hipError_t launch_sweep_f32(bool count, const SweepParams& p, int grid, hipStream_t st);
 int rowdot_run(int dt, const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d, float* out,
                hipStream_t st, hipError_t* herr);
 int sweep_debug_set(const char* name, long value);

@@ -1,11 +1,11 @@
 // Host side of the fused score-GEMM + top-k sweep: launch plan, workspace layout, the list merges and the
-// positive-score kernel.  The sweep kernels themselves live in sweep_kernels.h / topk_sweep4.inc.
+// positive-score kernel.  The sweep kernel itself lives in sweep_kernels.h / sweep16.inc.
 #include "sweep_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// Merge the 2*n_splits sorted lists of each query into out_val/out_idx.  One wave per query.
+// Merge the n_lists (= n_splits) sorted lists of each query into out_val/out_idx.  One wave per query.
 template <int EK>
-__global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, int n_lists,
+__global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, int n_lists, int cap,
                                                                 int64_t nq, int64_t nq_pad, int k, int64_t idx_offset,
                                                                 float* __restrict__ out_val, int64_t* __restrict__ out_idx,
                                                                 const uint32_t* __restrict__ rank_part,
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* 
 #pragma unroll
     for (int e = 0; e < EK; ++e) best[e] = 0ull;
     for (int l = 0; l < n_lists; ++l) {
-        const uint64_t* src = cand + ((int64_t)l * nq_pad + qr) * CAND_CAP;
+        const uint64_t* src = cand + ((int64_t)l * nq_pad + qr) * cap;
         uint64_t nw[EK];
 #pragma unroll
         for (int e = 0; e < EK; ++e) {
@@ -92,47 +92,63 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Positive scores with the arithmetic of the sweep: out[i] = (q[i] . c[i]) as the element (i, i) of a 32 x 32
-// score tile contracted by the SAME mma_step, fragments and k order as the sweep kernels (each 16-byte chunk
-// 2s+h of a 64-byte phase goes to lane half h of k-step s, phases and k-steps in row order), so that the value is
-// bit-identical to the score the filter sees for column i of query i.  The hard-negative rule compares every score
-// with 0.95 * scores[idx] taken out of the same GEMV (pretrain/create_negative_index.py:47-49): a positive score
-// from a different accumulation order can flip candidates within an ulp of the bound.
-// One wave per 32 row pairs; fragments straight from global memory (the rows are read once: no LDS stage).
+// Positive scores with the arithmetic of the sweep: out[i] = (q[i] . c[i]) as the element (i, i) of a 16 x 16 score
+// tile contracted by the SAME mma16, fragments and k order as the sweep kernel (the 16-byte chunk 4s + g4 of a row goes
+// to lane group g4 of k-step s, k-steps of 64 bytes in row order), so that the value is bit-identical to the score the
+// filter sees for column i of query i.  The hard-negative rule compares every score with 0.95 * scores[idx] taken out
+// of the same GEMV (pretrain/create_negative_index.py:47-49): a positive score from a different accumulation order
+// can flip candidates within an ulp of the bound.
+// One wave per 16 row pairs; fragments straight from global memory (the rows are read once: no LDS stage).
 template <int DT>
 __global__ __launch_bounds__(256) void rowdot_mma_kernel(const char* __restrict__ q, const char* __restrict__ c,
                                                          const float* __restrict__ qs, const float* __restrict__ cs,
                                                          int64_t n, int rowbytes, float* __restrict__ out) {
-    typedef typename Acc<DT>::type acc_t;
-    const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    typedef typename Acc16<DT>::type acc_t;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g4 = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (row0 >= n) return;
-    const int64_t row = row0 + l31 < n ? row0 + l31 : n - 1;       // clamped rows compute garbage nobody stores
-    const char* ap = c + row * rowbytes + 16 * h;                   // corpus rows on the MFMA row axis, as in the sweep
-    const char* bp = q + row * rowbytes + 16 * h;
+    const int64_t row = row0 + l15 < n ? row0 + l15 : n - 1;       // clamped rows compute garbage nobody stores
+    const char* ap = c + row * rowbytes + 16 * g4;                  // corpus rows on the MFMA row axis, as in the sweep
+    const char* bp = q + row * rowbytes + 16 * g4;
     acc_t acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    for (int r = 0; r < 4; ++r) acc[r] = 0;
     for (int off = 0; off < rowbytes; off += 128) {                 // rowbytes % 128 == 0 (checked by the caller)
-        v4i a[4], b[4];
+        v4i a[2], b[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            a[s] = *(const v4i*)(ap + off + 32 * s);
-            b[s] = *(const v4i*)(bp + off + 32 * s);
+        for (int s = 0; s < 2; ++s) {
+            a[s] = *(const v4i*)(ap + off + 64 * s);
+            b[s] = *(const v4i*)(bp + off + 64 * s);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) mma_step<DT>(acc, a[s], b[s]);
+        for (int s = 0; s < 2; ++s) {
+            mma16<DT, 0>(acc, a[s], b[s]);
+            if constexpr (DT == ABC_DT_F32) {
+                mma16<DT, 1>(acc, a[s], b[s]);
+                mma16<DT, 2>(acc, a[s], b[s]);
+                mma16<DT, 3>(acc, a[s], b[s]);
+            }
+        }
     }
-    // element (i, i): column l31 = i lives in the lane with h = (i >> 2) & 1, register (i & 3) + 4 * (i >> 3)
-    const int rsel = (l31 & 3) + 4 * (l31 >> 3);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");            // the last MFMA's result (hipcc pads nothing for asm)
+    // element (i, i): column l15 = i lives in lane group g4 = i >> 2, register i & 3
     float v = 0.f;
     int vi = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (r == rsel) {
-            if constexpr (DT == ABC_DT_I8) vi = acc[r]; else v = acc[r];
+    for (int r = 0; r < 4; ++r) {
+        if constexpr (DT == ABC_DT_I8) {
+            int x;
+            const int src = acc[r];
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(src));
+            if (r == (l15 & 3)) vi = x;
+        } else {
+            float x;
+            const float src = acc[r];
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(src));
+            if (r == (l15 & 3)) v = x;
         }
-    if (h == ((l31 >> 2) & 1) && row0 + l31 < n) {
+    }
+    if (g4 == (l15 >> 2) && row0 + l15 < n) {
         if constexpr (DT == ABC_DT_I8) out[row] = (float)vi * (qs[row] * cs[row]);
         else out[row] = v;
     }
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(256) void rowdot_mma_kernel(const char* __restrict_
 int rowdot_run(int dt, const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d, float* out,
                hipStream_t st, hipError_t* herr) {
     const int rowbytes = d * (dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 ? 1 : 4));
-    const unsigned grid = (unsigned)((n + 127) / 128);
+    const unsigned grid = (unsigned)((n + 63) / 64);
     if (dt == ABC_DT_BF16) hipLaunchKernelGGL(rowdot_mma_kernel<ABC_DT_BF16>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
     else if (dt == ABC_DT_F32) hipLaunchKernelGGL(rowdot_mma_kernel<ABC_DT_F32>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
     else hipLaunchKernelGGL(rowdot_mma_kernel<ABC_DT_I8>, dim3(grid), dim3(256), 0, st, (const char*)q, (const char*)c, qs, cs, n, rowbytes, out);
@@ -155,7 +171,7 @@ int rowdot_run(int dt, const void* q, const float* qs, const void* c, const floa
 // ------------------------------------------------------------------------------------------------
 static int elem_bytes(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 ? 1 : 4); }
 
-// Tuning / diagnostics knobs.  The environment (ABC_SWEEP4, ABC_DEBUG_FLAGS, ABC_PLAN_QB) is read ONCE, when the
+// Tuning / diagnostics knobs.  The environment (ABC_DEBUG_FLAGS, ABC_PLAN_QB) is read ONCE, when the
 // library is loaded; afterwards only abc_debug_set() changes them (tests and timing scripts).  Flags that make
 // results wrong (1: no epilogue, 2: nothing appended) exist only in -DABC_DIAG builds: a production library masks
 // them out, so a stray environment variable cannot corrupt a search.
@@ -165,13 +181,10 @@ static int elem_bytes(int dt) { return dt == ABC_DT_BF16 ? 2 : (dt == ABC_DT_I8 
 #define ABC_FLAG_MASK (~3)
 #endif
 struct SweepTuning {
-    std::atomic<int> sweep4{-1};       // -1: by sweep length, 0 / 1: force the 8-wave / one-wave-per-SIMD kernel
     std::atomic<int> flags{0};         // SweepParams::debug_flags
     std::atomic<int> plan_qb{0};       // > 0: query blocks per launch (timing experiments)
     SweepTuning() {
-        const char* e = getenv("ABC_SWEEP4");
-        if (e && *e) sweep4 = atoi(e) != 0;
-        e = getenv("ABC_DEBUG_FLAGS");
+        const char* e = getenv("ABC_DEBUG_FLAGS");
         if (e && *e) flags = atoi(e) & ABC_FLAG_MASK;
         e = getenv("ABC_PLAN_QB");
         if (e && atoi(e) >= 8) plan_qb = atoi(e);
@@ -181,15 +194,13 @@ static SweepTuning g_tuning;            // constructed at load time
 
 int sweep_debug_set(const char* name, long value) {
     if (!name) return ABC_E_INVALID;
-    if (!strcmp(name, "sweep4")) g_tuning.sweep4 = value < 0 ? -1 : (value != 0);
-    else if (!strcmp(name, "flags")) g_tuning.flags = (int)value & ABC_FLAG_MASK;
+    if (!strcmp(name, "flags")) g_tuning.flags = (int)value & ABC_FLAG_MASK;
     else if (!strcmp(name, "plan_qb")) g_tuning.plan_qb = value >= 8 ? (int)value : 0;
     else return ABC_E_INVALID;
     return ABC_OK;
 }
 long sweep_debug_get(const char* name) {
     if (!name) return -2;
-    if (!strcmp(name, "sweep4")) return g_tuning.sweep4;
     if (!strcmp(name, "flags")) return g_tuning.flags;
     if (!strcmp(name, "plan_qb")) return g_tuning.plan_qb;
     return -2;
@@ -198,9 +209,9 @@ long sweep_debug_get(const char* name) {
 void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl) {
     pl->n_tiles = (int)((nc + TILE - 1) / TILE);
     const int64_t qblocks_total = (nq + TILE - 1) / TILE;
-    // at most 32 query blocks per launch (k <= 64: 8 splits, 16 lists per query) or 16 (k > 64: 16 splits, 32
-    // lists), so that every list publishes its 4th best or better: the tracked bounds are exact down to rank 4
-    // and loose below (int8 10M x 3584, k = 100: +13 %).  Blocks are spread evenly over the launches (98 blocks ->
+    // at most 32 query blocks per launch (k <= 64: 8 splits = 8 lists per query) or 16 (k > 64: 16 splits), so that
+    // every list publishes its 8th best or better (pub_m = ceil(k / n_lists) <= 8: the tracked bounds come from the 4 x 4
+    // best scores the four lanes of a query remember).  Blocks are spread evenly over the launches (98 blocks ->
     // 25+25+24+24, not 32+32+32+2: a 2-block launch fills 40 of the 256 CUs)
     {
         const int64_t max_qb = k > 64 ? 16 : 32;
@@ -226,28 +237,17 @@ void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl) {
 size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k) {
     SweepPlan pl;
     sweep_plan(nq, nc, k, &pl);
-    const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
+    const size_t lists = (size_t)pl.n_splits * pl.nq_pad;
     return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
 }
 
 
-// Which sweep kernel a launch takes.  Both produce the same lists and the same result; the one-wave-per-SIMD kernel
-// (topk_sweep4.inc) is 1-2 % faster on long sweeps (mining shape, 1611 tiles per split: +2 %; 402: +0.5 %; int8 10 M: +1.6 %) and slower
-// on short ones (412 k rows per shard: -1 %; eval-sized corpora: its first-tile work is twice as large per wave).
-// ABC_SWEEP4=0 / 1 forces one of them (tests run both).
-static bool use_sweep4(const SweepParams& p) {
-    const int f = g_tuning.sweep4;
-    if (f >= 0) return f != 0;
-    return p.n_tiles / (p.n_splits > 0 ? p.n_splits : 1) >= 384;
-}
-
-// The sweep kernels are instantiated in sweep_inst_{bf16,i8,f32}.hip (one translation unit per element type, so that
+// The sweep kernel is instantiated in sweep_inst_{bf16,i8,f32}.hip (one translation unit per element type, so that
 // they build in parallel); each exports one launcher.
 static hipError_t launch_sweep(int dt, bool count, const SweepParams& p, int grid, hipStream_t st) {
-    const bool four = use_sweep4(p);
-    if (dt == ABC_DT_BF16) return launch_sweep_bf16(count, four, p, grid, st);
-    if (dt == ABC_DT_I8) return launch_sweep_i8(count, four, p, grid, st);
-    return launch_sweep_f32(count, four, p, grid, st);
+    if (dt == ABC_DT_BF16) return launch_sweep_bf16(count, p, grid, st);
+    if (dt == ABC_DT_I8) return launch_sweep_i8(count, p, grid, st);
+    return launch_sweep_f32(count, p, grid, st);
 }
 
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
@@ -257,7 +257,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     SweepPlan pl;
     sweep_plan(nq, nc, k, &pl);
     const int rowbytes = d * elem_bytes(dt);
-    const size_t lists = (size_t)2 * pl.n_splits * pl.nq_pad;
+    const size_t lists = (size_t)pl.n_splits * pl.nq_pad;
     uint64_t* cand = (uint64_t*)workspace;
     uint32_t* rank_part = (uint32_t*)(cand + lists * CAND_CAP);
     float* pub = (float*)(rank_part + lists);
@@ -272,7 +272,6 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         p.nq = nq_l;
         p.nc = nc;
         p.rowbytes = rowbytes;
-        p.nk = rowbytes / ROWB;
         p.k = k;
         p.n_qblocks = (int)((nq_l + TILE - 1) / TILE);
         p.n_splits = pl.n_splits;
@@ -284,7 +283,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         p.rank_ref = count ? rank_ref + q0 : nullptr;
         p.rank_excl = (rank_self_offset == INT64_MIN) ? INT64_MIN / 2 : rank_self_offset + q0;
         p.debug_flags = g_tuning.flags;
-        p.n_lists = 2 * pl.n_splits;
+        p.n_lists = pl.n_splits;
         p.pub_m = (k + p.n_lists - 1) / p.n_lists;
         p.pub = pub;
         {   // published bounds start at -inf (0xFF800000) for every launch
@@ -300,11 +299,11 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
         const int mgrid = (int)((nq_l + 3) / 4);
         if (k <= 64)
-            hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, 2 * pl.n_splits, nq_l,
+            hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
                                pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
                                count ? out_rank + q0 : nullptr);
         else
-            hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, 2 * pl.n_splits, nq_l,
+            hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
                                pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
                                count ? out_rank + q0 : nullptr);
         e = hipGetLastError();

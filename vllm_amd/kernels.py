@@ -165,7 +165,7 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
 
 
 def debug_set(name: str, value: int) -> None:
-    """Diagnostics hook of the library (tests, timing scripts): "sweep4" -1/0/1, "flags", "plan_qb"."""
+    """Diagnostics hook of the library (tests, timing scripts): "flags", "plan_qb"."""
     _lib.check(_lib.load().abc_debug_set(name.encode(), int(value)), "abc_debug_set")
 
 
