@@ -108,6 +108,23 @@ int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq,
                    float* out_val, int64_t* out_idx, void* stream);
 
 /*
+ * The same search with PACKED output, and the merge of packed lists: the multi-GPU exchange (no
+ * counterpart in the reference, whose search runs on one GPU).  A shard's result travels as ONE tensor of 8 bytes per
+ * entry, so a chunk's exchange is one all-gather of k * 8 bytes per query:
+ *   key = orderable(score) << 32 | (0xFFFFFFFF - global index),  0 = no entry;  larger key = better (ties: smaller index)
+ *   orderable(s) = bits(s) ^ (bits(s) >> 31 ? 0xFFFFFFFF : 0x80000000)
+ * abc_topk_packed: dtype = ABC_DT_*, q_scale / c_scale only for int8; idx_offset + nc must not exceed 2^32 - 1
+ *   (ABC_E_INVALID otherwise: the index field has 32 bits).  out_keys [nq,k] u64, best first.
+ * abc_topk_merge_packed: keys [parts,nq,k] u64 (each list sorted descending) -> out_val [nq,k] f32 (-inf = missing),
+ *   out_idx [nq,k] i64 (-1 = missing).
+ */
+int abc_topk_packed(int dtype, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale,
+                    int64_t nc, int d, int k, const float* upper_bound, int64_t idx_offset, uint64_t* out_keys,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int abc_topk_merge_packed(const uint64_t* keys, int parts, int64_t nq, int k, float* out_val, int64_t* out_idx,
+                          void* stream);
+
+/*
  * Diagnostics hook for tests and timing scripts (no counterpart in the reference; not for production use: it
  * changes process-wide settings, do not call it while another thread is inside abc_topk_*):
  *   "flags"   SweepParams::debug_flags (cycle stamps, refresh spacing, XCD grouping; result-altering bits are

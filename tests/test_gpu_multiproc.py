@@ -91,3 +91,43 @@ def test_differentiable_gather_under_process_group(world):
         assert torch.allclose(o["dq"], qs[r].grad, rtol=1e-3, atol=2e-6)
         assert torch.allclose(o["dc"], cs[r].grad, rtol=1e-3, atol=2e-6)     # gradients from EVERY rank's loss
         assert abs(float(o["dtemp"]) - float(temps[r].temp.grad)) <= 1e-3 * abs(float(temps[r].temp.grad)) + 1e-5
+
+
+def _mine_rank(rank, world, port, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vllm_amd import parallel, search
+    q, c = oracle.make_clustered(700, 6000, 256, seed=91, n_centres=12)
+    c[4100] = c[33]                                            # a tie across shards
+    lo, hi = parallel.shard_bounds(c.shape[0], world, rank)
+    qe = search.Embeddings(q, "bf16", "cuda:0")
+    sc = parallel.ShardedCorpus(search.Embeddings(c[lo:hi], "bf16", "cuda:0"), lo, c.shape[0])
+    idx, vals, s_pos = sc.mine_negatives(qe, 48, chunk=256)    # 3 chunks: the pipelined exchange, ragged last chunk
+    torch.cuda.synchronize()
+    ret[rank] = (idx.cpu(), vals.cpu(), s_pos.cpu())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_mining_under_process_group(world):
+    """parallel.ShardedCorpus with the production kernels: every rank sweeps its corpus shard, the lists cross as
+    packed 8-byte keys in ONE all-gather per query chunk, merges run behind the next chunk's sweep; every rank ends
+    with the single-GPU result (search.mine_negatives over the whole corpus), bit for bit."""
+    from vllm_amd import search
+    q, c = oracle.make_clustered(700, 6000, 256, seed=91, n_centres=12)
+    c[4100] = c[33]
+    qe, ce = search.Embeddings(q, "bf16", "cuda:0"), search.Embeddings(c, "bf16", "cuda:0")
+    want = [t.cpu() for t in search.mine_negatives(qe, ce, 48)]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mine_rank, args=(world, 29970 + world, ret), nprocs=world, join=True)
+    for r in range(world):
+        idx, vals, s_pos = ret[r]
+        assert torch.equal(idx, want[0]), r
+        assert torch.equal(vals, want[1]), r
+        assert torch.equal(s_pos, want[2]), r

@@ -118,3 +118,33 @@ def test_workspace_is_per_stream():
     torch.cuda.synchronize()
     assert torch.equal(got1[0], want1[0]) and torch.equal(got1[1], want1[1])
     assert torch.equal(got2[0], want2[0]) and torch.equal(got2[1], want2[1])
+
+
+@pytest.mark.parametrize("compute,d", [("bf16", 1024), ("f32", 256), ("i8", 3584)])
+def test_packed_shards_merge_to_the_single_sweep(compute, d):
+    """abc_topk_packed per corpus shard + abc_topk_merge_packed == abc_topk_* over the whole corpus, bit for bit
+    (values AND indices, ties included: the packed key orders equal scores by global index), with the 0.95 bound on;
+    and the packed form of one shard decodes to what the unpacked entry returns for it."""
+    from vllm_amd import kernels, search
+    nq, nc, k = 300, 5000, 64
+    q, c = oracle.make_clustered(nq, nc, d, seed=5 + d, n_centres=10)
+    c[1200] = c[3900] = c[17]                          # exact ties across shards
+    qe = search.Embeddings(q, compute, DEV)
+    ce = search.Embeddings(c, compute, DEV)
+    ub = search.positive_scores(qe, ce) * 0.95
+    want_v, want_i, _ = kernels.topk(qe.data, ce.data, k, upper_bound=ub, q_scale=qe.scale, c_scale=ce.scale)
+    cuts = [0, 1300, 1301, 4000, nc]                   # ragged shards, one of a single row (shorter than k)
+    keys = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        sh = ce.rows(lo, hi)
+        kp = kernels.topk_packed(qe.data, sh.data, k, upper_bound=ub, idx_offset=lo, q_scale=qe.scale, c_scale=sh.scale)
+        assert kp.dtype == torch.int64 and tuple(kp.shape) == (nq, k)
+        v1, i1, _ = kernels.topk(qe.data, sh.data, k, upper_bound=ub, idx_offset=lo, q_scale=qe.scale, c_scale=sh.scale)
+        dv, di = kernels.merge_packed(kp[None])
+        assert torch.equal(di, i1) and torch.equal(dv, v1)
+        keys.append(kp)
+    got_v, got_i = kernels.merge_packed(torch.stack(keys))
+    assert torch.equal(got_i, want_i)
+    assert torch.equal(got_v, want_v)
+    with pytest.raises(Exception):                     # a global index that does not fit the key's 32 bits
+        kernels.topk_packed(qe.data, ce.data, k, idx_offset=(1 << 32) - 10, q_scale=qe.scale, c_scale=ce.scale)

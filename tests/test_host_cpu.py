@@ -106,7 +106,31 @@ def _worker(rank, world, port, ret):
         o2 = torch.argsort(v, dim=1, descending=True, stable=True)
         return torch.gather(v, 1, o2)[:, :k].contiguous(), torch.gather(i, 1, o2)[:, :k].contiguous()
 
-    be = parallel.Backend(topk=_topk, rowdot=lambda a, b: (a.data * b.data).sum(-1), merge=_merge)
+    # the packed pair, restated with numpy: key = orderable(score) << 32 | (0xFFFFFFFF - index), 0 = no entry
+    import numpy as np
+
+    def _pack(v, i):
+        u = v.numpy().view(np.uint32).astype(np.uint64)
+        o = np.where(u >> 31, u ^ np.uint64(0xFFFFFFFF), u ^ np.uint64(0x80000000))
+        key = (o << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - i.numpy().astype(np.uint64))
+        return torch.from_numpy(np.where(i.numpy() >= 0, key, np.uint64(0)).view(np.int64))
+
+    def _topk_packed(qe, ce, k, ub, off):
+        v, i = _topk(qe, ce, k, ub, off)
+        return _pack(v.float().contiguous(), i)
+
+    def _merge_packed(keys):
+        parts, nq, k = keys.shape
+        kk = np.sort(keys.numpy().view(np.uint64).transpose(1, 0, 2).reshape(nq, parts * k), axis=1)[:, ::-1][:, :k]
+        o = (kk >> np.uint64(32)).astype(np.uint32)
+        u = np.where(o >> 31, o ^ np.uint32(0x80000000), o ^ np.uint32(0xFFFFFFFF))
+        v = torch.from_numpy(np.where(kk != 0, u.view(np.float32), -np.inf).astype(np.float32))
+        i = torch.from_numpy(np.where(kk != 0, (np.uint64(0xFFFFFFFF) - (kk & np.uint64(0xFFFFFFFF))).astype(np.int64), -1))
+        return v, i
+
+    packed = os.environ.get("ABC_TEST_PACKED") == "1"
+    be = parallel.Backend(topk=_topk, rowdot=lambda a, b: (a.data * b.data).sum(-1), merge=_merge,
+                          topk_packed=_topk_packed if packed else None, merge_packed=_merge_packed if packed else None)
     sc = parallel.ShardedCorpus(_Emb(c[lo:hi]), lo, c.shape[0], backend=be)
     idx, vals, s_pos = sc.mine_negatives(_Emb(q), 16, ratio=0.95, offset=3, fill_masked_tail=False)
     # chunked + overlapped exchange gives the same lists as one exchange
@@ -117,12 +141,15 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_mining_exchange_gloo(world):
+@pytest.mark.parametrize("world,packed", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_mining_exchange_gloo(world, packed, monkeypatch):
+    """The exchange logic with an exact checker bound in place of the kernels: the two-tensor form and the packed form
+    (ONE all-gather of 8-byte keys per chunk, merges pipelined behind the next chunk's sweep)."""
     import oracle
+    monkeypatch.setenv("ABC_TEST_PACKED", "1" if packed else "0")
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29650 + world, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29650 + world + (10 if packed else 0), ret), nprocs=world, join=True)
     q, c = oracle.make_clustered(40, 301, 64, seed=6, n_centres=4)
     c[100] = c[200]
     c[8] = -q[5]

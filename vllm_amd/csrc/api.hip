@@ -46,15 +46,29 @@ __global__ void fill_empty_kernel(float* v, int64_t* ix, int64_t n, int64_t* ran
     if (rank && i < nq) rank[i] = 0;
 }
 
+__global__ void fill_zero_keys_kernel(uint64_t* keys, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = 0ull;
+}
+
 static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc,
-                      int d, int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
+                      int d, int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx, uint64_t* out_keys,
                       const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_common(nq, nc, d, k, dt);
     if (rc) return rc;
     if (nq == 0) return ABC_OK;
-    if (!out_val || !out_idx) return fail(ABC_E_INVALID, "null output pointer");
+    if (out_keys) {
+        if (idx_offset < 0 || idx_offset + nc > 0xFFFFFFFFll)
+            return fail(ABC_E_INVALID, "packed keys: idx_offset + nc = %lld exceeds the 32-bit index field (2^32-1)", (long long)(idx_offset + nc));
+    } else if (!out_val || !out_idx) return fail(ABC_E_INVALID, "null output pointer");
     if ((rank_ref == nullptr) != (out_rank == nullptr)) return fail(ABC_E_INVALID, "rank_ref and out_rank must be given together");
     hipStream_t st = (hipStream_t)stream;
+    if (nc == 0 && out_keys) {
+        const int64_t n = nq * k;
+        hipLaunchKernelGGL(fill_zero_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_keys, n);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "fill_zero_keys");
+    }
     if (nc == 0) {
         const int64_t n = nq * k;
         hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out_val, out_idx, n, out_rank, nq);
@@ -68,7 +82,7 @@ static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const 
     if (!ws || ws_bytes < need) return abc_fail_ws(need, ws_bytes);
     if ((uintptr_t)ws & 15) return fail(ABC_E_INVALID, "workspace must be 16-byte aligned");
     hipError_t he = hipSuccess;
-    rc = sweep_run(dt, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, st, &he);
+    rc = sweep_run(dt, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, out_keys, rank_ref, rank_self_offset, out_rank, ws, st, &he);
     if (rc == ABC_E_HIP) return abc_fail_hip(he, "topk sweep launch");
     return rc;
 }
@@ -76,18 +90,38 @@ static int topk_entry(int dt, const void* q, const float* qs, int64_t nq, const 
 extern "C" int abc_topk_bf16(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
                              int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
                              int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
-    return topk_entry(ABC_DT_BF16, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
+    return topk_entry(ABC_DT_BF16, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, nullptr, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 extern "C" int abc_topk_f32(const void* q, int64_t nq, const void* c, int64_t nc, int d, int k, const float* ub,
                             int64_t idx_offset, float* out_val, int64_t* out_idx, const float* rank_ref,
                              int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes, void* stream) {
-    return topk_entry(ABC_DT_F32, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
+    return topk_entry(ABC_DT_F32, q, nullptr, nq, c, nullptr, nc, d, k, ub, idx_offset, out_val, out_idx, nullptr, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
 }
 extern "C" int abc_topk_i8(const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc, int d,
                            int k, const float* ub, int64_t idx_offset, float* out_val, int64_t* out_idx,
                            const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* ws, size_t ws_bytes,
                            void* stream) {
-    return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
+    return topk_entry(ABC_DT_I8, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, out_val, out_idx, nullptr, rank_ref, rank_self_offset, out_rank, ws, ws_bytes, stream);
+}
+
+// Packed output for the cross-GPU exchange: out_keys[nq,k] = orderable(score) << 32 | (0xFFFFFFFF - global index), 0 = no entry.
+extern "C" int abc_topk_packed(int dtype, const void* q, const float* qs, int64_t nq, const void* c, const float* cs, int64_t nc,
+                               int d, int k, const float* ub, int64_t idx_offset, uint64_t* out_keys, void* ws, size_t ws_bytes,
+                               void* stream) {
+    if (!out_keys && nq > 0) return fail(ABC_E_INVALID, "null output pointer");
+    return topk_entry(dtype, q, qs, nq, c, cs, nc, d, k, ub, idx_offset, nullptr, nullptr, out_keys, nullptr, INT64_MIN, nullptr, ws,
+                      ws_bytes, stream);
+}
+
+extern "C" int abc_topk_merge_packed(const uint64_t* keys, int parts, int64_t nq, int k, float* out_val, int64_t* out_idx,
+                                     void* stream) {
+    if (parts < 1 || nq < 0 || k < 1 || k > ABC_MAX_K) return fail(ABC_E_INVALID, "bad merge shape parts=%d nq=%lld k=%d", parts, (long long)nq, k);
+    if (nq == 0) return ABC_OK;
+    if (!keys || !out_val || !out_idx) return fail(ABC_E_INVALID, "null pointer");
+    hipError_t he = hipSuccess;
+    int rc = merge_keys_run(keys, parts, nq, k, out_val, out_idx, (hipStream_t)stream, &he);
+    if (rc == ABC_E_HIP) return abc_fail_hip(he, "merge launch");
+    return rc;
 }
 
 extern "C" int abc_topk_merge(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, int64_t idx_limit,

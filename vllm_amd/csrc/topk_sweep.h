@@ -48,7 +48,7 @@ struct SweepPlan {
 void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl);
 size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k);
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
-              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx, uint64_t* out_keys,
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
               hipError_t* herr);
 hipError_t launch_sweep_bf16(bool count, const SweepParams& p, int grid, hipStream_t st);
@@ -56,6 +56,8 @@ hipError_t launch_sweep_i8(bool count, const SweepParams& p, int grid, hipStream
 hipError_t launch_sweep_f32(bool count, const SweepParams& p, int grid, hipStream_t st);
 int rowdot_run(int dt, const void* q, const float* qs, const void* c, const float* cs, int64_t n, int d, float* out,
                hipStream_t st, hipError_t* herr);
+int merge_keys_run(const uint64_t* keys, int parts, int64_t nq, int k, float* out_val, int64_t* out_idx, hipStream_t st,
+                   hipError_t* herr);
 int sweep_debug_set(const char* name, long value);
 long sweep_debug_get(const char* name);
 int merge_lists_run(const float* vals, const int64_t* idx, int parts, int64_t nq, int k, float* out_val,

@@ -8,6 +8,7 @@ template <int EK>
 __global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, int n_lists, int cap,
                                                                 int64_t nq, int64_t nq_pad, int k, int64_t idx_offset,
                                                                 float* __restrict__ out_val, int64_t* __restrict__ out_idx,
+                                                                uint64_t* __restrict__ out_keys,
                                                                 const uint32_t* __restrict__ rank_part,
                                                                 int64_t* __restrict__ out_rank) {
     const int lane = threadIdx.x & 63;
@@ -37,8 +38,14 @@ __global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* 
         const int i = e * 64 + lane;
         if (i < k) {
             const uint64_t kk = best[e];
-            out_val[qr * k + i] = kk ? key_val(kk) : -INFINITY;
-            out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) + idx_offset : -1;
+            if (out_keys) {
+                // packed form for the cross-GPU exchange: the index field becomes 0xFFFFFFFF - (index + idx_offset), i.e. the
+                // key minus the offset (no borrow: the host checked idx_offset + nc <= 0xFFFFFFFF); 0 stays "no entry"
+                out_keys[qr * k + i] = kk ? kk - (uint64_t)idx_offset : 0ull;
+            } else {
+                out_val[qr * k + i] = kk ? key_val(kk) : -INFINITY;
+                out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) + idx_offset : -1;
+            }
         }
     }
     if (out_rank != nullptr && lane == 0) {
@@ -89,6 +96,54 @@ __global__ __launch_bounds__(256) void topk_merge_lists_kernel(const float* __re
             out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) : -1;
         }
     }
+}
+
+// Merge `parts` packed key lists per query (each sorted descending, 0 = no entry) -- the merge after ONE all-gather of
+// 8 bytes per entry.
+template <int EK>
+__global__ __launch_bounds__(256) void topk_merge_keys_kernel(const uint64_t* __restrict__ keys, int parts, int64_t nq, int k,
+                                                              float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qr >= nq) return;
+    uint64_t best[EK];
+#pragma unroll
+    for (int e = 0; e < EK; ++e) best[e] = 0ull;
+    for (int l = 0; l < parts; ++l) {
+        const uint64_t* src = keys + ((int64_t)l * nq + qr) * k;
+        uint64_t nw[EK];
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const int i = e * 64 + lane;
+            nw[e] = (i < k) ? src[i] : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < EK; ++e) {
+            const uint64_t rev = shfl_u64(nw[EK - 1 - e], 63 - lane);
+            best[e] = best[e] > rev ? best[e] : rev;
+        }
+        wave_bitonic_merge_desc<EK>(best, lane);
+    }
+#pragma unroll
+    for (int e = 0; e < EK; ++e) {
+        const int i = e * 64 + lane;
+        if (i < k) {
+            const uint64_t kk = best[e];
+            out_val[qr * k + i] = kk ? key_val(kk) : -INFINITY;
+            out_idx[qr * k + i] = kk ? (int64_t)key_idx(kk) : -1;
+        }
+    }
+}
+
+int merge_keys_run(const uint64_t* keys, int parts, int64_t nq, int k, float* out_val, int64_t* out_idx, hipStream_t st,
+                   hipError_t* herr) {
+    const int mgrid = (int)((nq + 3) / 4);
+    if (mgrid == 0) return ABC_OK;
+    if (k <= 64) hipLaunchKernelGGL(topk_merge_keys_kernel<1>, dim3(mgrid), dim3(256), 0, st, keys, parts, nq, k, out_val, out_idx);
+    else hipLaunchKernelGGL(topk_merge_keys_kernel<2>, dim3(mgrid), dim3(256), 0, st, keys, parts, nq, k, out_val, out_idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
+    return ABC_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,7 +306,7 @@ static hipError_t launch_sweep(int dt, bool count, const SweepParams& p, int gri
 }
 
 int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const void* c, const float* c_scale, int64_t nc,
-              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx,
+              int d, int k, const float* upper_bound, int64_t idx_offset, float* out_val, int64_t* out_idx, uint64_t* out_keys,
               const float* rank_ref, int64_t rank_self_offset, int64_t* out_rank, void* workspace, hipStream_t st,
               hipError_t* herr) {
     SweepPlan pl;
@@ -300,11 +355,13 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         const int mgrid = (int)((nq_l + 3) / 4);
         if (k <= 64)
             hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
-                               pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
+                               pl.nq_pad, k, idx_offset, out_val ? out_val + q0 * k : nullptr, out_idx ? out_idx + q0 * k : nullptr,
+                               out_keys ? out_keys + q0 * k : nullptr, rank_part,
                                count ? out_rank + q0 : nullptr);
         else
             hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
-                               pl.nq_pad, k, idx_offset, out_val + q0 * k, out_idx + q0 * k, rank_part,
+                               pl.nq_pad, k, idx_offset, out_val ? out_val + q0 * k : nullptr, out_idx ? out_idx + q0 * k : nullptr,
+                               out_keys ? out_keys + q0 * k : nullptr, rank_part,
                                count ? out_rank + q0 : nullptr);
         e = hipGetLastError();
         if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }

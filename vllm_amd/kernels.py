@@ -100,6 +100,54 @@ def topk(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.T
     return out_val, out_idx, out_rank
 
 
+def topk_packed(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.Tensor] = None, idx_offset: int = 0,
+                q_scale: Optional[torch.Tensor] = None, c_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same search with packed output: int64 [nq, k] holding the library's 64-bit keys (orderable score << 32 |
+    0xFFFFFFFF - global index, 0 = no entry), the form a shard's lists cross the GPUs in (ONE tensor of 8 B per entry)."""
+    _need_gpu(q, c, upper_bound, q_scale, c_scale)
+    if q.dtype != c.dtype or q.dtype not in _DT:
+        raise _lib.AbcError(f"unsupported dtypes {q.dtype}/{c.dtype}")
+    if q.dim() != 2 or c.dim() != 2 or q.shape[1] != c.shape[1] or c.device != q.device:
+        raise _lib.AbcError(f"shape/device mismatch {tuple(q.shape)} on {q.device} vs {tuple(c.shape)} on {c.device}")
+    lib = _lib.load()
+    q, c = q.contiguous(), c.contiguous()
+    nq, d = q.shape
+    nc = c.shape[0]
+    dt = _DT[q.dtype]
+    keys = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    if upper_bound is not None:
+        upper_bound = upper_bound.to(torch.float32).contiguous()
+    if dt == _lib.DT_I8:
+        if q_scale is None or c_scale is None:
+            raise _lib.AbcError("int8 search needs q_scale and c_scale")
+        q_scale, c_scale = q_scale.to(torch.float32).contiguous(), c_scale.to(torch.float32).contiguous()
+    need = lib.abc_topk_workspace_bytes(nq, nc, d, k, dt)
+    if need == 0:
+        _lib.check(-1, "abc_topk_workspace_bytes")
+    with _on(q):
+        ws = workspace(need, q.device)
+        rc = lib.abc_topk_packed(dt, q.data_ptr(), _ptr(q_scale), nq, c.data_ptr(), _ptr(c_scale), nc, d, k, _ptr(upper_bound),
+                                 int(idx_offset), keys.data_ptr(), ws.data_ptr(), ws.numel(), _stream(q))
+    _lib.check(rc, "abc_topk_packed")
+    return keys
+
+
+def merge_packed(keys: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge [parts, nq, k] packed key lists (each sorted descending) into values f32 [nq, k] / indices i64 [nq, k]."""
+    _need_gpu(keys)
+    lib = _lib.load()
+    keys = keys.contiguous()
+    if keys.dtype != torch.int64 or keys.dim() != 3:
+        raise _lib.AbcError("merge_packed: expected int64 [parts, nq, k]")
+    parts, nq, k = keys.shape
+    out_val = torch.empty((nq, k), dtype=torch.float32, device=keys.device)
+    out_idx = torch.empty((nq, k), dtype=torch.int64, device=keys.device)
+    with _on(keys):
+        rc = lib.abc_topk_merge_packed(keys.data_ptr(), parts, nq, k, out_val.data_ptr(), out_idx.data_ptr(), _stream(keys))
+    _lib.check(rc, "abc_topk_merge_packed")
+    return out_val, out_idx
+
+
 def rowdot(q: torch.Tensor, c: torch.Tensor, q_scale=None, c_scale=None) -> torch.Tensor:
     """out[i] = q[i] . c[i] (fp32).  The positive score of row-aligned pairs."""
     _need_gpu(q, c)

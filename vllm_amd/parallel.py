@@ -3,8 +3,8 @@ backend "nccl" is RCCL over xGMI on ROCm).
 
 The reference searches on a single GPU (script/embed_for_neg_mining.sh:16); sharding is the build's
 own multi-GPU form: every rank holds rows [lo, hi) of the corpus, sees every query,
-produces a local top-k with GLOBAL indices, and the per-rank lists are exchanged with ONE all-gather
-and merged on the device (abc_topk_merge).  The 0.95-positive rule needs s_pos[i] = q_i . c_i, which
+produces a local top-k with GLOBAL indices as packed 8-byte keys, and the per-rank lists are exchanged with ONE
+all-gather per chunk and merged on the device (abc_topk_packed / abc_topk_merge_packed).  The 0.95-positive rule needs s_pos[i] = q_i . c_i, which
 only the shard owning row i can compute: owners fill their rows, one all-reduce(SUM) replicates it.
 """
 from __future__ import annotations
@@ -33,6 +33,9 @@ class Backend:
     topk: Callable          # (q, c_shard, k, upper_bound, idx_offset) -> (vals [nq,k], idx [nq,k] global, -1 = hole)
     rowdot: Callable        # (q_rows, c_rows) -> [n] f32
     merge: Callable         # (vals [P,nq,k], idx [P,nq,k], idx_limit) -> (vals [nq,k], idx [nq,k])
+    # the packed pair: one 8-byte key per entry (score and global index), so that a chunk's exchange is ONE all-gather
+    topk_packed: Optional[Callable] = None     # (q, c_shard, k, upper_bound, idx_offset) -> keys i64 [nq,k]
+    merge_packed: Optional[Callable] = None    # (keys [P,nq,k]) -> (vals [nq,k], idx [nq,k])
 
 
 def hip_backend() -> Backend:
@@ -45,7 +48,13 @@ def hip_backend() -> Backend:
     def _rowdot(q, c):
         return kernels.rowdot(q.data, c.data, q_scale=q.scale, c_scale=c.scale)
 
-    return Backend(topk=_topk, rowdot=_rowdot, merge=kernels.merge_topk)
+    def _topk_packed(q, c, k, ub, off):
+        if q.compute != c.compute:
+            raise ValueError("query and corpus must use the same compute dtype")
+        return kernels.topk_packed(q.data, c.data, k, upper_bound=ub, idx_offset=off, q_scale=q.scale, c_scale=c.scale)
+
+    return Backend(topk=_topk, rowdot=_rowdot, merge=kernels.merge_topk, topk_packed=_topk_packed,
+                   merge_packed=kernels.merge_packed)
 
 
 class ShardedCorpus:
@@ -101,40 +110,55 @@ class ShardedCorpus:
 
     def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None, chunk: int = 8192
              ) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Exact global top-k of every query, replicated on every rank.  Queries go through the local
-        sweep in chunks; the exchange of chunk i (ONE all-gather of its (value f32, index i64) lists) is
-        enqueued asynchronously and overlaps the sweep of chunk i+1; the P-way merges run at the end."""
+        """Exact global top-k of every query, replicated on every rank.  Queries go through the local sweep in chunks;
+        a chunk's lists leave the sweep as packed 8-byte keys (score and global index) and cross the GPUs in ONE
+        all-gather of k * 8 bytes per query, enqueued asynchronously; while chunk i+1 sweeps, chunk i's gather completes
+        and its P-way merge is enqueued, so at most two chunks' buffers are alive.  (A backend without the packed pair --
+        CPU-side tests of the exchange logic -- exchanges (value f32, index i64) with two all-gathers.)"""
         n = q.shape[0]
         if self.world == 1:
             return self.backend.topk(q, self.shard, k, upper_bound, self.lo)
-        pending = []
+        packed = self.backend.topk_packed is not None and self.backend.merge_packed is not None
+        outs_v, outs_i = [], []
+        pending = None
+
+        def finish(p):
+            works, bufs, keep, dev, rows = p
+            for w in works:
+                w.wait()
+            bufs = [b.to(dev) for b in bufs]
+            if packed:
+                mv, mi = self.backend.merge_packed(bufs[0].view(self.world, rows, k))
+            else:
+                mv, mi = self.backend.merge(bufs[0].view(self.world, rows, k), bufs[1].view(self.world, rows, k), self.n_total)
+            outs_v.append(mv)
+            outs_i.append(mi)
+
         for a in range(0, max(n, 1), chunk):
             b = min(n, a + chunk)
             qc = q if (a == 0 and b == n) else q.rows(a, b)
             ub = None if upper_bound is None else upper_bound[a:b]
-            v, i = self.backend.topk(qc, self.shard, k, ub, self.lo)
-            dev = v.device
-            if self._host_staged(v):                        # gloo: the lists cross in host memory
-                v, i = v.cpu(), i.cpu()
-            v, i = v.contiguous(), i.contiguous()
-            gv = torch.empty((self.world * v.shape[0], k), dtype=v.dtype, device=v.device)
-            gi = torch.empty((self.world * i.shape[0], k), dtype=i.dtype, device=i.device)
-            wv = dist.all_gather_into_tensor(gv, v, group=self.group, async_op=True)
-            wi = dist.all_gather_into_tensor(gi, i, group=self.group, async_op=True)
-            pending.append((wv, wi, gv, gi, v, i, dev))     # v, i stay alive until the collective has read them
-        outs_v, outs_i = [], []
-        for wv, wi, gv, gi, v, i, dev in pending:
-            wv.wait()
-            wi.wait()
-            gv, gi = gv.to(dev), gi.to(dev)
-            mv, mi = self.backend.merge(gv.view(self.world, v.shape[0], k), gi.view(self.world, i.shape[0], k), self.n_total)
-            outs_v.append(mv)
-            outs_i.append(mi)
+            if packed:
+                parts = [self.backend.topk_packed(qc, self.shard, k, ub, self.lo)]
+            else:
+                parts = list(self.backend.topk(qc, self.shard, k, ub, self.lo))
+            dev = parts[0].device
+            if self._host_staged(parts[0]):                 # gloo: the lists cross in host memory
+                parts = [t.cpu() for t in parts]
+            parts = [t.contiguous() for t in parts]
+            bufs = [torch.empty((self.world * t.shape[0], k), dtype=t.dtype, device=t.device) for t in parts]
+            works = [dist.all_gather_into_tensor(g, t, group=self.group, async_op=True) for g, t in zip(bufs, parts)]
+            if pending is not None:                         # chunk i-1: its gather has had this chunk's sweep to complete
+                finish(pending)
+            pending = (works, bufs, parts, dev, b - a)      # parts stay alive until the collective has read them
+        if pending is not None:
+            finish(pending)
         if len(outs_v) == 1:
             return outs_v[0], outs_i[0]
         return torch.cat(outs_v, dim=0), torch.cat(outs_i, dim=0)
 
-    def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0, fill_masked_tail: bool = True):
+    def mine_negatives(self, q, k: int, ratio: float = 0.95, offset: int = 0, fill_masked_tail: bool = True,
+                       chunk: int = 8192):
         """Sharded form of pretrain/create_negative_index.py:45-52 for queries whose positives are
         corpus rows offset .. offset+n-1.  Returns (idx, vals, s_pos), identical on every rank and identical
         to search.mine_negatives on the unsharded corpus: rows with fewer than k survivors get their tail filled
@@ -143,7 +167,7 @@ class ShardedCorpus:
         from .search import fill_masked_tail_rows
         s_pos = self.positive_scores(q, offset)
         ub = s_pos * ratio
-        v, i = self.topk(q, k, upper_bound=ub)
+        v, i = self.topk(q, k, upper_bound=ub, chunk=chunk)
         if fill_masked_tail and self.world > 1:
             fill_masked_tail_rows(i, ub, lambda rows: self.topk(q.take(rows), k))
         elif fill_masked_tail:
