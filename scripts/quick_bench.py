@@ -34,6 +34,9 @@ if dtype == "i8":
         css.append(b)
     c, cs = torch.cat(cc), torch.cat(css)
     kw = dict(q_scale=qs, c_scale=cs)
+import os
+if os.environ.get("QB_UB"):                      # a constant upper bound for every query (e.g. -2: nothing survives the filter)
+    kw["upper_bound"] = torch.full((nq,), float(os.environ["QB_UB"]), device=dev)
 torch.cuda.synchronize()
 for it in range(iters + 1):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

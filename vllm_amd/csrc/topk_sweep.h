@@ -36,6 +36,7 @@ struct SweepParams {
     unsigned long long* dbg; // debug counters
     uint64_t* cand;         // [n_splits][nq_pad][CAND_CAP] packed keys
     uint32_t* rank_part;    // [n_splits][nq_pad]
+    uint32_t* list_cnt;     // [n_splits][nq_pad] entries each list holds when the sweep ends (unsorted; the merge selects)
 };
 
 struct SweepPlan {

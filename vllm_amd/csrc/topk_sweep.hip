@@ -3,36 +3,68 @@
 #include "sweep_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// Merge the n_lists (= n_splits) sorted lists of each query into out_val/out_idx.  One wave per query.
+// Select the top k of each query from its n_lists (= n_splits) candidate lists as the sweep left them: list l holds
+// list_cnt[l][q] keys in no order.  One wave per query: entries are filtered with the query's final bound (the minimum of
+// the bounds its lists published: at least k entries reach it, so nothing below it can be in the top k), the survivors
+// are packed through a per-wave LDS stage and folded 64 at a time (sort + bitonic merge) into the running top k.
 template <int EK>
-__global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, int n_lists, int cap,
+__global__ __launch_bounds__(256) void topk_merge_packed_kernel(const uint64_t* __restrict__ cand, const uint32_t* __restrict__ list_cnt,
+                                                                const float* __restrict__ pub, int n_lists, int cap,
                                                                 int64_t nq, int64_t nq_pad, int k, int64_t idx_offset,
                                                                 float* __restrict__ out_val, int64_t* __restrict__ out_idx,
                                                                 uint64_t* __restrict__ out_keys,
                                                                 const uint32_t* __restrict__ rank_part,
                                                                 int64_t* __restrict__ out_rank) {
+    __shared__ uint64_t stage_all[4][128];
     const int lane = threadIdx.x & 63;
     const int64_t qr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qr >= nq) return;
+    uint64_t* const stage = stage_all[threadIdx.x >> 6];
+    float mn = INFINITY;
+    for (int l = lane; l < n_lists; l += 64) mn = fminf(mn, pub[qr * n_lists + l]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+    // key of the smallest score that can still be in the top k (keys order like scores; any index): pass = key >= kmin
+    // (a bound of +-0 admits both zeros: fmax/fmin do not keep the sign the keys order by)
+    const uint64_t kmin = (mn == -INFINITY) ? 0ull : ((uint64_t)f32_orderable(mn == 0.f ? -0.f : mn) << 32);
     uint64_t best[EK];
 #pragma unroll
     for (int e = 0; e < EK; ++e) best[e] = 0ull;
+    auto fold = [&](uint64_t chunk) {                    // 64 keys, any order
+        uint64_t c1[1] = {chunk};
+        wave_sort_desc<1>(c1, lane);
+        // best (desc) against the reversed chunk (zeros first for EK = 2): the element-wise max is bitonic and holds the top
+        const uint64_t rev = shfl_u64(c1[0], 63 - lane);
+        best[EK - 1] = best[EK - 1] > rev ? best[EK - 1] : rev;
+        wave_bitonic_merge_desc<EK>(best, lane);
+    };
+    int ns = 0;
     for (int l = 0; l < n_lists; ++l) {
         const uint64_t* src = cand + ((int64_t)l * nq_pad + qr) * cap;
-        uint64_t nw[EK];
-#pragma unroll
-        for (int e = 0; e < EK; ++e) {
-            const int i = e * 64 + lane;
-            nw[e] = (i < k) ? src[i] : 0ull;
+        int n = (int)list_cnt[(int64_t)l * nq_pad + qr];
+        n = n < cap ? n : cap;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const uint64_t key = (i < n) ? src[i] : 0ull;
+            const bool keep = key != 0ull && key >= kmin;
+            const uint64_t bal = __ballot(keep);
+            if (keep) stage[ns + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = key;
+            ns += __builtin_popcountll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (ns >= 64) {
+                const uint64_t chunk = stage[lane];
+                const uint64_t up = (64 + lane < ns) ? stage[64 + lane] : 0ull;
+                __builtin_amdgcn_wave_barrier();
+                stage[lane] = up;
+                ns -= 64;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                fold(chunk);
+            }
         }
-        // best (desc) vs reversed new list: element-wise max is bitonic and holds the top 64*EK
-#pragma unroll
-        for (int e = 0; e < EK; ++e) {
-            const uint64_t rev = shfl_u64(nw[EK - 1 - e], 63 - lane);
-            best[e] = best[e] > rev ? best[e] : rev;
-        }
-        wave_bitonic_merge_desc<EK>(best, lane);
     }
+    if (ns > 0) fold(lane < ns ? stage[lane] : 0ull);
 #pragma unroll
     for (int e = 0; e < EK; ++e) {
         const int i = e * 64 + lane;
@@ -293,7 +325,7 @@ size_t sweep_workspace_bytes(int64_t nq, int64_t nc, int k) {
     SweepPlan pl;
     sweep_plan(nq, nc, k, &pl);
     const size_t lists = (size_t)pl.n_splits * pl.nq_pad;
-    return lists * CAND_CAP * sizeof(uint64_t) + lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
+    return lists * CAND_CAP * sizeof(uint64_t) + 2 * lists * sizeof(uint32_t) + lists * sizeof(float) + 256;
 }
 
 
@@ -316,7 +348,8 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
     uint64_t* cand = (uint64_t*)workspace;
     uint32_t* rank_part = (uint32_t*)(cand + lists * CAND_CAP);
     float* pub = (float*)(rank_part + lists);
-    unsigned long long* dbg = (unsigned long long*)(((uintptr_t)(pub + lists) + 15) & ~(uintptr_t)15);
+    uint32_t* list_cnt = (uint32_t*)(pub + lists);
+    unsigned long long* dbg = (unsigned long long*)(((uintptr_t)(list_cnt + lists) + 15) & ~(uintptr_t)15);
     const bool count = rank_ref != nullptr && out_rank != nullptr;
 
     for (int64_t q0 = 0; q0 < nq; q0 += pl.nq_pad) {
@@ -349,17 +382,18 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         if (p.debug_flags & 16) (void)hipMemsetAsync(dbg, 0, 176, st);
         p.cand = cand;
         p.rank_part = rank_part;
+        p.list_cnt = list_cnt;
         const int grid = p.n_qblocks * p.n_splits;
         hipError_t e = launch_sweep(dt, count, p, grid, st);
         if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
         const int mgrid = (int)((nq_l + 3) / 4);
         if (k <= 64)
-            hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
+            hipLaunchKernelGGL(topk_merge_packed_kernel<1>, dim3(mgrid), dim3(256), 0, st, cand, list_cnt, pub, p.n_lists, CAND_CAP, nq_l,
                                pl.nq_pad, k, idx_offset, out_val ? out_val + q0 * k : nullptr, out_idx ? out_idx + q0 * k : nullptr,
                                out_keys ? out_keys + q0 * k : nullptr, rank_part,
                                count ? out_rank + q0 : nullptr);
         else
-            hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, p.n_lists, CAND_CAP, nq_l,
+            hipLaunchKernelGGL(topk_merge_packed_kernel<2>, dim3(mgrid), dim3(256), 0, st, cand, list_cnt, pub, p.n_lists, CAND_CAP, nq_l,
                                pl.nq_pad, k, idx_offset, out_val ? out_val + q0 * k : nullptr, out_idx ? out_idx + q0 * k : nullptr,
                                out_keys ? out_keys + q0 * k : nullptr, rank_part,
                                count ? out_rank + q0 : nullptr);
@@ -371,12 +405,11 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
             unsigned long long hc[21] = {0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hc, dbg, sizeof(hc), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[abc debug] appends=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[1], hc[2]);
-            fprintf(stderr, "[abc debug] wave-cycles: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu total=%llu clock=%.3f GHz\n",
+            fprintf(stderr, "[abc debug] appends=%llu block descents=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[19], hc[1], hc[2]);
+            fprintf(stderr, "[abc debug] wave-clocks: filter=%llu flush=%llu compact=%llu refresh=%llu final=%llu total=%llu clock=%.3f GHz\n",
                     hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], 0.1 * (double)hc[8] / (double)(hc[9] ? hc[9] : 1));
-            fprintf(stderr, "[abc debug] of which tiles 1-4: filter=%llu flush=%llu compact=%llu refresh=%llu end-barrier=%llu\n",
-                    hc[14], hc[15], hc[16], hc[17], hc[18]);
-            if (hc[10]) fprintf(stderr, "[abc debug] phase stamps: R(read+issue+vmwait)=%llu barrier1=%llu M=%llu barrier2(+E)=%llu\n", hc[10], hc[11], hc[12], hc[13]);
+            fprintf(stderr, "[abc debug] of which tiles 1-4: filter=%llu flush=%llu compact=%llu refresh=%llu\n",
+                    hc[14], hc[15], hc[16], hc[17]);
         }
     }
     return ABC_OK;
