@@ -296,12 +296,12 @@ long sweep_debug_get(const char* name) {
 void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl) {
     pl->n_tiles = (int)((nc + TILE - 1) / TILE);
     const int64_t qblocks_total = (nq + TILE - 1) / TILE;
-    // at most 32 query blocks per launch (k <= 64: 8 splits = 8 lists per query) or 16 (k > 64: 16 splits), so that
-    // every list publishes its 8th best or better (pub_m = ceil(k / n_lists) <= 8: the tracked bounds come from the 4 x 4
-    // best scores the four lanes of a query remember).  Blocks are spread evenly over the launches (98 blocks ->
-    // 25+25+24+24, not 32+32+32+2: a 2-block launch fills 40 of the 256 CUs)
+    // at most 32 query blocks per launch (8 splits = 8 lists per query), so that every list publishes its 16th best or
+    // better (pub_m = ceil(k / n_lists) <= 16 for k <= 128: the tracked bounds come from the 4 x 4 best scores the four
+    // lanes of a query remember).  Blocks are spread evenly over the launches (98 blocks -> 25+25+24+24, not
+    // 32+32+32+2: a 2-block launch fills 40 of the 256 CUs)
     {
-        const int64_t max_qb = k > 64 ? 16 : 32;
+        const int64_t max_qb = 32;
         const int64_t launches = (qblocks_total + max_qb - 1) / max_qb;
         int64_t per = launches > 0 ? (qblocks_total + launches - 1) / launches : 1;
         // multiples of 8 keep the XCD-aware block mapping, which only a long sweep profits from
