@@ -1,4 +1,4 @@
-"""Timing of the rank-counting (COUNT) sweep variants at the bench shape: ABC_SWEEP4=0/1 python scripts/count_bench.py"""
+"""Timing of the rank-counting (COUNT) sweep variants at the bench shape: python scripts/count_bench.py"""
 import sys, torch
 sys.path.insert(0, ".")
 from vllm_amd import kernels
