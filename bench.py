@@ -108,16 +108,19 @@ def main():
 
     # time the sweep (the dominant kernel) on its own with events on the launch stream
     sweep_ms = []
-    inner_topk = corpus.backend.topk
 
-    def timed_topk(q, c, k, ub, off):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = inner_topk(q, c, k, ub, off)
-        e1.record()
-        sweep_ms.append((e0, e1))
-        return out
-    corpus.backend.topk = timed_topk
+    def timed(inner):
+        def run(q, c, k, ub, off):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner(q, c, k, ub, off)
+            e1.record()
+            sweep_ms.append((e0, e1))
+            return out
+        return run
+    corpus.backend.topk = timed(corpus.backend.topk)                    # N = 1: sweep + merge to (values, indices)
+    if corpus.backend.topk_packed is not None:
+        corpus.backend.topk_packed = timed(corpus.backend.topk_packed)  # N > 1: sweep + merge to packed keys
 
     bq = QUERIES_PER_GPU_STEP * world
     batches = []
@@ -165,6 +168,8 @@ def main():
     # per step: every sweep launch of the step (N > 1 sweeps the step's queries in chunks of 8192)
     sweep_avg_ms = sum(a.elapsed_time(b) for a, b in sweep_ms) / max(args.steps, 1)
     flops_per_step = 2.0 * (n_queries / max(args.steps, 1)) * (hi - lo) * D   # algorithmic: 2*Nc_local*D per query
+    if sweep_avg_ms <= 0:
+        raise SystemExit("bench.py: no sweep launch was timed (the timing hook missed the backend's entry point)")
     achieved = flops_per_step / (sweep_avg_ms * 1e-3) / 1e12
     launches_per_step = max(len(sweep_ms) // max(args.steps, 1), 1)
     flops_per_launch = flops_per_step / launches_per_step
