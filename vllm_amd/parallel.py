@@ -73,9 +73,10 @@ class ShardedCorpus:
 
     # -- exchange steps -------------------------------------------------------------------------
     def _host_staged(self, t: torch.Tensor) -> bool:
-        """gloo's collectives on device tensors do not complete reliably on this stack (all-gather: both ranks sit in
-        wait(); all-reduce: hangs with four ranks on one GPU), so with a gloo group (rehearsals, CPU-side tests)
-        device tensors are exchanged through host copies.
+        """Under a gloo group (rehearsals on one GPU, CPU-side tests) device tensors cross in host memory.  A single gloo
+        collective on device tensors completes; what deadlocks is several ASYNCHRONOUS ones outstanding while the main
+        thread keeps enqueueing kernels (gloo stages device tensors on its own worker threads and synchronises streams
+        there): scripts/gloo_device_diag.py, DESIGN.md section 5.
         RCCL (backend "nccl", the production path) takes the device tensors as they are."""
         return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
 
