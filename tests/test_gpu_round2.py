@@ -148,3 +148,32 @@ def test_packed_shards_merge_to_the_single_sweep(compute, d):
     assert torch.equal(got_v, want_v)
     with pytest.raises(Exception):                     # a global index that does not fit the key's 32 bits
         kernels.topk_packed(qe.data, ce.data, k, idx_offset=(1 << 32) - 10, q_scale=qe.scale, c_scale=ce.scale)
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f32", "i8"])
+def test_rank_count_excludes_the_own_column_only(compute):
+    """neg_mine.batch's rank (neg_mine.py:21-42): columns scoring above rank_ref, the query's own positive column
+    excluded.  With a reference 0.01 BELOW the positive's score the own column would count: the count with the exclusion
+    is exactly one less than without it, for every query, wherever the own columns lie (three different tiles here), and
+    both agree with the fp64 count outside the rounding gap.  (The kernel tests indices only in the one tile per sweep
+    that holds some query's own column.)"""
+    from vllm_amd import kernels, search
+    nq, nc, d, off = 400, 2500, 128 if compute != "i8" else 256, 700
+    q, c = oracle.make_clustered(nq, nc, d, seed=61, n_centres=8)
+    c[off:off + nq] = torch.nn.functional.normalize(q + 0.3 * torch.randn(nq, d, generator=torch.Generator().manual_seed(5)), dim=-1)
+    q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+    qe, ce = search.Embeddings(q, compute, DEV), search.Embeddings(c, compute, DEV)
+    s_pos = search.positive_scores(qe, ce, off)
+    ref = (s_pos - 0.01).contiguous()
+    kw = dict(q_scale=qe.scale, c_scale=ce.scale)
+    _, _, r_ex = kernels.topk(qe.data, ce.data, 8, rank_ref=ref, rank_self_offset=off, **kw)
+    _, _, r_all = kernels.topk(qe.data, ce.data, 8, rank_ref=ref, **kw)
+    assert torch.equal(r_all - r_ex, torch.ones_like(r_ex))
+    if compute != "i8":
+        s = oracle.scores_f32(q, c, fp64=True)
+        own = torch.zeros_like(s, dtype=torch.bool)
+        own[torch.arange(nq), off + torch.arange(nq)] = True
+        gap = (s - ref.cpu().double()[:, None]).abs() > 2e-5
+        lo = ((s > ref.cpu().double()[:, None]) & gap & ~own).sum(1)
+        hi = (((s > ref.cpu().double()[:, None]) | ~gap) & ~own).sum(1)
+        assert bool(((r_ex.cpu() >= lo) & (r_ex.cpu() <= hi)).all())

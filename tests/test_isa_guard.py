@@ -65,7 +65,11 @@ def test_phase_loop_is_clean(isa, dt, mfma, per_phase):
     assert re.search(mfma + r" a\[", text), "accumulators not in AGPRs"
 
 
-def test_main_variants_do_not_spill_vectors(isa):
+def test_no_variant_spills_vectors(isa):
+    """Neither the search/mining kernels nor the rank-counting (COUNT) ones touch scratch.  The COUNT variants spilled
+    35 VGPRs in round 1 and 93-141 midway through round 2: hipcc hoisted the 16 column indices of every block's
+    own-positive test out of the tile loop; the test now runs only in the one tile that holds such a column."""
     for dt in (0, 1, 2):
-        body = _kernel(isa, dt, 0)
-        assert "scratch_" not in body, f"dtype {dt}: vector spills in the mining/search variant"
+        for count in (0, 1):
+            body = _kernel(isa, dt, count)
+            assert "scratch_" not in body, f"dtype {dt} count {count}: vector spills"
