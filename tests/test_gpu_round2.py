@@ -177,3 +177,71 @@ def test_rank_count_excludes_the_own_column_only(compute):
         lo = ((s > ref.cpu().double()[:, None]) & gap & ~own).sum(1)
         hi = (((s > ref.cpu().double()[:, None]) | ~gap) & ~own).sum(1)
         assert bool(((r_ex.cpu() >= lo) & (r_ex.cpu() <= hi)).all())
+
+
+@pytest.mark.parametrize("compute,k", [("bf16", 64), ("bf16", 128), ("i8", 100), ("f32", 64)])
+def test_ascending_scores_over_many_tiles_per_split(compute, k):
+    """The epilogue's worst case on a FULL launch (32 query blocks x 8 splits, 12 tiles per split): every query's scores
+    ascend with the row index, so every tile beats every bound -- dense blocks (wave-uniform append loop, queue full,
+    direct appends), list overflow (a compaction every other tile) and the selecting merge on long unsorted lists all
+    run.  The small adversarial test of round 1 had one tile per split."""
+    from vllm_amd import search
+    nq, nc, d = 8192, 96 * 256 + 77, 128 if compute != "i8" else 256
+    g = torch.Generator().manual_seed(9)
+    u = torch.nn.functional.normalize(torch.randn(d, generator=g), dim=0)
+    q = torch.nn.functional.normalize(u[None] + 0.01 * torch.randn(nq, d, generator=g) / d ** 0.5, dim=-1)
+    alpha = torch.linspace(0.05, 0.95, nc)
+    w = torch.randn(nc, d, generator=g)
+    w = torch.nn.functional.normalize(w - (w @ u)[:, None] * u[None], dim=-1)
+    c = torch.nn.functional.normalize(alpha[:, None] * u[None] + (1 - alpha ** 2).sqrt()[:, None] * w, dim=-1)
+    q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+    qe, ce = search.Embeddings(q, compute, DEV), search.Embeddings(c, compute, DEV)
+    v, i, _ = search.topk(qe, ce, k)
+    torch.cuda.synchronize()
+    if compute == "i8":
+        rv, ri = oracle.topk_ref_i8(qe.data.cpu(), qe.scale.cpu(), ce.data.cpu(), ce.scale.cpu(), k)
+        assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu(), ri)
+    else:
+        sub = torch.arange(0, nq, 16)                      # 512 queries through the fp64 checker
+        oracle.check_topk_parity(q[sub], c, v.cpu()[sub], i.cpu()[sub], rtol=2e-5)
+        # every query: k distinct in-range indices, scores sorted, and (nearly) the last rows of the corpus
+        ic = i.cpu()
+        assert int(ic.min()) >= 0 and int(ic.max()) < nc
+        assert bool((ic.sort(dim=1).values.diff(dim=1) > 0).all())
+        assert bool((v.cpu().diff(dim=1) <= 0).all())
+        assert float((ic >= nc - 8 * k).float().mean()) > 0.9
+
+
+def test_random_shapes_against_the_oracle():
+    """Twenty seeded random problems (ragged query blocks and tiles, k from 1 to 128, corpora shorter than k, with and
+    without the 0.95 bound, all three compute types) through search.topk / mine_negatives against the fp64 checker."""
+    from vllm_amd import search
+    rng = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))  # noqa: E731
+    for case in range(20):
+        compute = ("bf16", "f32", "i8")[case % 3]
+        d = (64, 128, 256)[ri(0, 2)] * (2 if compute == "i8" else 1)
+        nq = (ri(1, 300), ri(300, 2000), ri(7000, 9000))[ri(0, 2)]
+        nc = (ri(1, 200), ri(200, 5000), ri(5000, 40000))[ri(0, 2)]
+        k = (ri(1, 16), ri(16, 64), ri(65, 128))[ri(0, 2)]
+        q, c = oracle.make_clustered(nq, nc, d, seed=1000 + case, n_centres=ri(1, 24))
+        q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+        qe, ce = search.Embeddings(q, compute, DEV), search.Embeddings(c, compute, DEV)
+        bound = case % 2 == 1 and nc >= nq
+        tag = (case, compute, nq, nc, d, k, bound)
+        if bound:
+            idx, vals, s_pos = search.mine_negatives(qe, ce, k, fill_masked_tail=False)
+            ub = (s_pos * 0.95).cpu()
+        else:
+            vals, idx, _ = search.topk(qe, ce, k)
+            ub = None
+        torch.cuda.synchronize()
+        vals, idx = vals.cpu(), idx.cpu()
+        assert tuple(idx.shape) == (nq, k), tag
+        if compute == "i8":
+            rv, rix = oracle.topk_ref_i8(qe.data.cpu(), qe.scale.cpu(), ce.data.cpu(), ce.scale.cpu(), k, upper_bound=ub)
+            assert torch.equal(vals, rv) and torch.equal(idx, rix), tag
+        else:
+            sub = torch.arange(0, nq, max(nq // 256, 1))
+            oracle.check_topk_parity(q[sub], c, vals[sub], idx[sub], rtol=2e-5 if compute == "f32" else 1e-3,
+                                     upper_bound=None if ub is None else ub[sub], ub_slack=False, atol=5e-7)
