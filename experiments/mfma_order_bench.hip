@@ -56,9 +56,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int mb = 4 * q + ((ORDER == 5 && (nb & 1)) ? 3 - j : j);
-                        mma(acc[mb][nb], a[0][mb], b[0][nb]);
-                        mma(acc[mb][nb], a[1][mb], b[1][nb]);
+                        const int mb = 4 * q + ((ORDER >= 5 && (nb & 1)) ? 3 - j : j);
+                        const int kf = (ORDER == 6) ? (j & 1) : 0;      // 6: k-steps back and forth (changes the rounding order)
+                        mma(acc[mb][nb], a[kf][mb], b[kf][nb]);
+                        mma(acc[mb][nb], a[1 - kf][mb], b[1 - kf][nb]);
                     }
         } else {
 #pragma unroll
@@ -98,7 +99,7 @@ int main(int argc, char** argv) {
     hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep)
-        for (int order = 0; order < 6; ++order) {
+        for (int order = 0; order < 7; ++order) {
             hipEventRecord(e0);
             if (order == 0) hipLaunchKernelGGL(bench<0>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 1) hipLaunchKernelGGL(bench<1>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
@@ -106,6 +107,7 @@ int main(int argc, char** argv) {
             if (order == 3) hipLaunchKernelGGL(bench<3>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 4) hipLaunchKernelGGL(bench<4>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 5) hipLaunchKernelGGL(bench<5>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
+            if (order == 6) hipLaunchKernelGGL(bench<6>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
