@@ -19,10 +19,13 @@ __device__ __forceinline__ void mma(v4f& acc, const v4i& a, const v4i& b) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-template <int ORDER>
+template <int ORDER, int LDSR = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void bench(const v4i* frags, float* out, int iters,
                                                                                        unsigned long long* clk) {
     const int lane = threadIdx.x & 63;
+    __shared__ v4i lds[8192];                       // 128 KB of fragments for the LDS-read variant
+    if (LDSR) { for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = frags[i % 2560]; __syncthreads(); }
+    v4i sink = {0, 0, 0, 0};
     v4i a[2][16], b[2][4];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -47,6 +50,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int j = 0; j < 4; ++j) {
                         const int nb = (ORDER == 1 && (mb & 1)) ? 3 - j : j;
                         mma(acc[mb][nb], a[k][mb], b[k][nb]);
+                    }
+        } else if constexpr (ORDER >= 4 && LDSR > 0) {
+            // order 5 with LDSR ds_read_b128 per phase spread between the pairs (what the kernel's fragment refills cost)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int mb = 4 * q + ((nb & 1) ? 3 - j : j);
+                        mma(acc[mb][nb], a[0][mb], b[0][nb]);
+                        mma(acc[mb][nb], a[1][mb], b[1][nb]);
+                        const int pr = q * 16 + nb * 4 + j;
+                        if (pr * LDSR / 64 != (pr + 1) * LDSR / 64) {
+                            v4i r;
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((unsigned)(((pr * 67 + (it & 31) * 64 + lane) & 8191) * 16)));
+                            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                            sink ^= r;
+                        }
                     }
         } else if constexpr (ORDER >= 4) {
             // quarter-steps of 4 corpus tiles: query tile outer, corpus tile inner (5: back and forth), k-steps innermost
@@ -75,7 +97,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    float s = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float s = (float)(sink[0] ^ sink[1] ^ sink[2] ^ sink[3]) * 1e-30f;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
@@ -87,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     const int zeros = argc > 2 ? atoi(argv[2]) : 0;
-    std::vector<unsigned short> h(40 * 64 * 8);
+    std::vector<unsigned short> h(2560 * 8);
     srand(1);
     for (auto& x : h) {   // unit-norm-like bf16: gaussian-ish magnitude 1/64, random sign and mantissa
         float f = zeros ? 0.f : ((rand() / (float)RAND_MAX) - 0.5f) * 0.06f;
@@ -99,7 +122,7 @@ int main(int argc, char** argv) {
     hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep)
-        for (int order = 0; order < 7; ++order) {
+        for (int order = 0; order < 9; ++order) {
             hipEventRecord(e0);
             if (order == 0) hipLaunchKernelGGL(bench<0>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 1) hipLaunchKernelGGL(bench<1>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
@@ -108,6 +131,8 @@ int main(int argc, char** argv) {
             if (order == 4) hipLaunchKernelGGL(bench<4>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 5) hipLaunchKernelGGL(bench<5>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
             if (order == 6) hipLaunchKernelGGL(bench<6>, dim3(256), dim3(256), 0, 0, d, out, iters, clk);
+            if (order == 7) hipLaunchKernelGGL((bench<5, 40>), dim3(256), dim3(256), 0, 0, d, out, iters, clk);   // + 40 LDS reads / phase
+            if (order == 8) hipLaunchKernelGGL((bench<5, 20>), dim3(256), dim3(256), 0, 0, d, out, iters, clk);   // + 20
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
