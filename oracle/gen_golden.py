@@ -5,8 +5,10 @@ TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
     python oracle/gen_golden.py
 
 Imports ``model/abc_util.py`` (compute_contrastive_loss / compute_gathered_loss) and
-``visualization/neg_mine.py`` (batch) from the reference and stores inputs + outputs as
-small .npz files under tests/golden/.  Only data is stored, never reference source.
+``visualization/neg_mine.py`` (batch) from the reference, and compiles the hot-path function definitions of
+``evaluate/eval_mscoco.py``, ``evaluate/eval_flickr30k.py`` and ``pretrain/create_negative_index.py`` out of those
+files (their modules cannot be imported here), runs them on CPU and stores inputs + outputs as small files under
+tests/golden/.  Only data is stored, never reference source.
 """
 from __future__ import annotations
 
@@ -183,6 +185,170 @@ def gen_mean_pool(abc_util):
     np.savez_compressed(os.path.join(OUT, "mean_pool.npz"), **out)
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# a1 / a2 / a3 glue: evaluate/eval_mscoco.py, evaluate/eval_flickr30k.py, pretrain/create_negative_index.py.
+# These files cannot be imported as modules here (their module-level imports need transformers 4.44 / Python 3.12,
+# SURVEY.md 8c), but the hot-path FUNCTIONS in them are plain torch.  Their definitions are compiled straight out of
+# the reference files (ast: the named top-level `def`s only, nothing else of the module runs) and executed on CPU with
+# `.cuda()` / `.cpu()` as the identity.  Only inputs and outputs are stored.
+# ----------------------------------------------------------------------------------------------------------------
+def _ref_functions(relpath, names, env):
+    import ast
+    path = os.path.join(REF, relpath)
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), (relpath, [n.name for n in body])
+    ns = dict(env)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+@contextlib.contextmanager
+def _cuda_is_identity():
+    keep = torch.Tensor.cuda, torch.Tensor.cpu
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.cpu = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda, torch.Tensor.cpu = keep
+
+
+def _grid(shape, g, amp=127):
+    """Integers in [-amp, amp]: embeddings are grid / 128, so every product is a multiple of 2^-14 and every partial sum of
+    a d <= 64 dot product is exact in fp32 (and the values themselves in bf16): CPU BLAS and any MFMA order agree bit for
+    bit, and equal scores are TRUE ties."""
+    return torch.randint(-amp, amp + 1, shape, generator=g, dtype=torch.int64)
+
+
+def _exact_scores(a, b):
+    return a @ b.t()                                   # int64, units of 2^-14
+
+
+def _karpathy(n_img, g):
+    """A Karpathy-shaped split file: test / train / val images, 5 captions each, some caption strings used by two images
+    (the dict of get_topk_candidates collapses them, eval_mscoco.py:45-48)."""
+    images, n = [], 0
+    for i in range(n_img + 12):
+        split = "test" if i < n_img else ("train" if i % 2 else "val")
+        sents = []
+        for j in range(5):
+            raw = f"caption {n} of image {i}"
+            if split == "test" and i % 9 == 4 and j == 2:
+                raw = f"a shared caption {i // 18}"        # images 4 and 13, 22 and 31, ... share one string
+            sents.append({"raw": raw, "sentid": n, "imgid": i})
+            n += 1
+        images.append({"split": split, "filepath": "val2014", "filename": f"COCO_val2014_{i:012d}.jpg",
+                       "sentences": sents, "imgid": i})
+    return {"images": images, "dataset": "synthetic"}
+
+
+def gen_glue():
+    import json
+    import tqdm as _tqdm
+    D, n_img = 64, 60
+    fix = {}
+    # ---- a1 / a2: eval_mscoco / eval_flickr run whole, on a synthetic split and a table-lookup embedding function
+    for seed in range(1000, 1200):
+        g = torch.Generator().manual_seed(seed)
+        kj = _karpathy(n_img, g)
+        test = [x for x in kj["images"] if x["split"] == "test"]
+        caps = sorted({s["raw"] for x in test for s in x["sentences"]})
+        img_grid = _grid((n_img, D), g)
+        cap_grid = _grid((len(caps), D), g)
+        # positives: caption = its image + noise, so recall is neither 0 nor 1
+        cap_of = {c: i for i, c in enumerate(caps)}
+        for i, x in enumerate(test):
+            for s in x["sentences"]:
+                r = cap_of[s["raw"]]
+                cap_grid[r] = torch.clamp((img_grid[i] * (1 + (i + r) % 3)) // 16 + cap_grid[r] // 2, -127, 127)
+        # no exact ties around any cut the evaluation makes (k = 1, 5, 10), in either direction: the reference's topk
+        # order among ties is unspecified
+        text_rows = torch.tensor([cap_of[s["raw"]] for x in test for s in x["sentences"]])
+        S = _exact_scores(img_grid, cap_grid[text_rows])                  # i2t: duplicated strings = duplicated columns
+        ok = True
+        for M, ids in ((S, [s["raw"] for x in test for s in x["sentences"]]), (S.t().contiguous(), list(range(n_img)))):
+            top = torch.sort(M, dim=1, descending=True, stable=True)
+            for r in range(M.shape[0]):
+                v, ix = top.values[r, :12].tolist(), top.indices[r, :12].tolist()
+                for a in range(11):
+                    if v[a] == v[a + 1] and ids[ix[a]] != ids[ix[a + 1]]:
+                        ok = False
+        if ok:
+            break
+    assert ok, "no tie-free seed found"
+    fix["eval_seed"] = np.int64(seed)
+    fix["eval_img_grid"] = img_grid.numpy().astype(np.int8)
+    fix["eval_cap_grid"] = cap_grid.numpy().astype(np.int8)
+    fix["eval_caps"] = np.array(caps)
+    with open(os.path.join(OUT, "glue_karpathy.json"), "w") as f:
+        json.dump(kj, f)
+
+    img_emb = (img_grid.float() / 128).contiguous()
+    cap_emb = (cap_grid.float() / 128).contiguous()
+
+    def make_fxn(root, sub):
+        img_row = {os.path.join(root, sub if sub is not None else x["filepath"], x["filename"]): i for i, x in enumerate(test)}
+
+        def fxn(item, dtype="image"):
+            return img_emb[img_row[item]].unsqueeze(0) if dtype == "image" else cap_emb[cap_of[item]].unsqueeze(0)
+        return fxn
+
+    env = {"torch": torch, "os": os, "json": json, "tqdm": lambda x, **k: x}
+    json_path = os.path.join(OUT, "glue_karpathy.json")
+    root = os.path.dirname(json_path)
+    for name, rel, fn, var, sub in (("mscoco", "evaluate/eval_mscoco.py", "eval_mscoco", "MSCOCO_EVAL", None),
+                                    ("flickr", "evaluate/eval_flickr30k.py", "eval_flickr", "FLICKR_EVAL", "flickr30k_images")):
+        ns = _ref_functions(rel, ["intersect", "get_topk_candidates", fn], env)
+        os.environ[var] = json_path
+        buf = io.StringIO()
+        with _cuda_is_identity(), contextlib.redirect_stdout(buf):
+            ns[fn](make_fxn(root, sub))
+        fix[f"{name}_lines"] = np.array(buf.getvalue().splitlines())
+        # the dicts themselves (a1), ids as indices: image i / caption row of `caps`
+        fxn = make_fxn(root, sub)
+        paths = [os.path.join(root, sub if sub is not None else x["filepath"], x["filename"]) for x in test]
+        images = [(p_, fxn(p_, dtype="image")) for p_ in paths]
+        text = [(s["raw"], fxn(s["raw"], dtype="text")) for x in test for s in x["sentences"]]
+        if name == "mscoco":
+            with _cuda_is_identity():
+                for k in (1, 3, 5, 10):
+                    d_i2t = ns["get_topk_candidates"](images, text, k)
+                    d_t2i = ns["get_topk_candidates"](text, images, k)
+                    fix[f"i2t_k{k}"] = np.array([[cap_of[c] for c in d_i2t[p_]] for p_ in paths], dtype=np.int32)
+                    fix[f"t2i_k{k}"] = np.array([[paths.index(p_) for p_ in d_t2i[c]] for c in caps], dtype=np.int32)
+                    assert len(d_i2t) == n_img and len(d_t2i) == len(caps)      # duplicated strings collapsed
+                dflt = ns["get_topk_candidates"](images, text)                  # default k = 3
+                assert all(len(v) == 3 for v in dflt.values())
+
+    # ---- a3: negatives_for_sample on row-aligned pairs, with the edge cases of SURVEY.md 8a
+    ns = _ref_functions("pretrain/create_negative_index.py", ["negatives_for_sample"], {"torch": torch, "inf": float("inf")})
+    g = torch.Generator().manual_seed(2024)
+    N = 320
+    c_grid = _grid((N, D), g)
+    q_grid = torch.clamp(c_grid // 2 + _grid((N, D), g) // 3, -127, 127)        # row i of c is the positive of query i
+    q_grid[5] = -c_grid[5]                               # negative positive score: the threshold keeps the positive
+    q_grid[6] = torch.clamp(-c_grid[6] // 2 + _grid((1, D), g)[0] // 4, -127, 127)
+    c_grid[40] = c_grid[7]                               # duplicated corpus rows: exact ties in every query
+    c_grid[41] = c_grid[7]
+    c_grid[200] = c_grid[199]
+    q_grid[300] = 0                                      # all scores 0: the positive scores 0, threshold 0, nothing masked
+    c_grid[310:316] = c_grid[309]                        # six copies of a positive: near-duplicates above 0.95 * s_pos
+    q_grid[309] = c_grid[309]
+    qe, ce = (q_grid.float() / 128).contiguous(), (c_grid.float() / 128).contiguous()
+    negative_dict = {}
+    with _cuda_is_identity(), torch.no_grad():
+        for idx in range(N):
+            ns["negatives_for_sample"](idx, negative_dict, qe, ce.clone())
+    assert list(negative_dict) == list(range(N)) and all(len(v) == 100 for v in negative_dict.values())
+    fix["mine_q_grid"] = q_grid.numpy().astype(np.int8)
+    fix["mine_c_grid"] = c_grid.numpy().astype(np.int8)
+    fix["mine_negatives"] = np.array([negative_dict[i] for i in range(N)], dtype=np.int32)
+    fix["mine_json_sha256"] = np.array(__import__("hashlib").sha256(json.dumps(negative_dict).encode()).hexdigest())
+    np.savez_compressed(os.path.join(OUT, "glue.npz"), **fix)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
@@ -192,6 +358,7 @@ def main():
     gen_neg_mine(neg_mine)
     gen_gathered()
     gen_mean_pool(abc_util)
+    gen_glue()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

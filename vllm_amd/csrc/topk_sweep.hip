@@ -379,7 +379,7 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
             if (em != hipSuccess) { *herr = em; return ABC_E_HIP; }
         }
         p.dbg = dbg;
-        if (p.debug_flags & 112) (void)hipMemsetAsync(dbg, 0, 176, st);
+        if (p.debug_flags & 240) (void)hipMemsetAsync(dbg, 0, 176, st);
         p.cand = cand;
         p.rank_part = rank_part;
         p.list_cnt = list_cnt;
@@ -401,8 +401,8 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
         if (e != hipSuccess) { *herr = e; return ABC_E_HIP; }
     }
     {
-        if (g_tuning.flags & 112) {                     // debug only: synchronous read-back of the last launch's counters
-            unsigned long long hc[21] = {0};
+        if (g_tuning.flags & 240) {                     // debug only: synchronous read-back of the last launch's counters
+            unsigned long long hc[22] = {0};
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hc, dbg, sizeof(hc), hipMemcpyDeviceToHost);
             fprintf(stderr, "[abc debug] appends=%llu block descents=%llu compactions=%llu compacted_entries=%llu (last launch)\n", hc[0], hc[19], hc[1], hc[2]);
@@ -410,7 +410,8 @@ int sweep_run(int dt, const void* q, const float* q_scale, int64_t nq, const voi
                     hc[3], hc[4], hc[5], hc[6], hc[7], hc[8], 0.1 * (double)hc[8] / (double)(hc[9] ? hc[9] : 1));
             fprintf(stderr, "[abc debug] of which tiles 1-4: filter=%llu flush=%llu compact=%llu refresh=%llu\n",
                     hc[14], hc[15], hc[16], hc[17]);
-            if (hc[12] || hc[13]) fprintf(stderr, "[abc debug] descents: group tests=%llu append loops=%llu wave-clocks (stamps included)\n", hc[12], hc[13]);
+            if (g_tuning.flags & 128) fprintf(stderr, "[abc debug] quarter-steps: Q0=%llu Q1=%llu Q2=%llu Q3=%llu wave-clocks\n", hc[12], hc[13], hc[20], hc[21]);
+            else if (hc[12] || hc[13]) fprintf(stderr, "[abc debug] descents: group tests=%llu append loops=%llu wave-clocks (stamps included)\n", hc[12], hc[13]);
             if (hc[10] || hc[11]) fprintf(stderr, "[abc debug] phase loop: vmcnt(0) wait=%llu barrier=%llu wave-clocks\n", hc[10], hc[11]);
         }
     }
