@@ -96,6 +96,17 @@ def get_topk_candidates(queries: Sequence[Tuple[object, torch.Tensor]],
     return get_topk_candidates_multi(queries, candidates, (k,), compute=compute)[k]
 
 
+def _rows(embs, what: str) -> torch.Tensor:
+    """The [N, D] matrix of a list of embeddings: [1, D] (or [n, D]) pieces are concatenated (eval_mscoco.py:38-39), [D]
+    vectors stacked (the candidate form of mmeb_vqa.py:24).  One list holds one form."""
+    dims = {int(e.dim()) for e in embs}
+    if dims == {1}:
+        return torch.stack(tuple(embs), dim=0)
+    if dims == {2}:
+        return torch.cat(tuple(embs), dim=0)
+    raise AbcError(f"{what} embeddings must all be [D] vectors or all [n, D] matrices, got dims {sorted(dims)}")
+
+
 def get_topk_candidates_multi(queries, candidates, ks: Iterable[int], compute: str = "f32") -> Dict[int, Dict[object, list]]:
     """One search at max(ks), prefixes reused for the smaller k (the reference recomputes the whole
     matmul for every k in [1, 5, 10], eval_mscoco.py:76-77,87-88)."""
@@ -103,8 +114,8 @@ def get_topk_candidates_multi(queries, candidates, ks: Iterable[int], compute: s
     query_ids, query_embs = zip(*queries)
     candidate_ids, candidate_embs = zip(*candidates)
     dev = _device()
-    q = Embeddings(torch.cat(query_embs, dim=0), compute, dev)
-    c = Embeddings(torch.cat(candidate_embs, dim=0), compute, dev)
+    q = Embeddings(_rows(query_embs, "query"), compute, dev)
+    c = Embeddings(_rows(candidate_embs, "candidate"), compute, dev)
     kmax = ks[-1]
     _, idx, _ = topk(q, c, kmax)
     idx = idx.cpu().tolist()
