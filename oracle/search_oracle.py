@@ -203,8 +203,13 @@ def quantize_i8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 def scores_i8(qa: torch.Tensor, sa: torch.Tensor, qb: torch.Tensor, sb: torch.Tensor) -> torch.Tensor:
     """score_ij = float(sum_k qa_ik*qb_jk) * (sa_i * sb_j); int32 sum exact, two fp32 multiplies."""
-    acc = (qa.to(torch.int32) @ qb.to(torch.int32).t()) if qa.shape[1] * 127 * 127 < 2 ** 31 else None
-    assert acc is not None
+    assert qa.shape[1] * 127 * 127 < 2 ** 31
+    if qa.shape[0] * qb.shape[0] * qa.shape[1] > (1 << 30):
+        # large cases: the same exact integer sums through the fp64 BLAS (|sum| < 2^31 << 2^53, every partial sum an exact
+        # integer), converted to fp32 exactly as the int32 sum would be (one round-to-nearest-even)
+        acc = qa.double() @ qb.double().t()
+    else:
+        acc = qa.to(torch.int32) @ qb.to(torch.int32).t()
     return acc.to(torch.float32) * (sa.float().unsqueeze(1) * sb.float().unsqueeze(0))
 
 

@@ -94,12 +94,12 @@ def test_upper_bound_rule_at_full_size(data):
 
 
 def test_int8_config_properties():
-    """BASELINE configs[4] shape (int8, d = 3584, k = 100, per-vector scales) on 4 M rows: sortedness, exact
+    """BASELINE configs[4] at its full size (int8, 10 M rows x d = 3584, k = 100, per-vector scales; 35.8 GB): sortedness, exact
     agreement of the returned scores with the int8 rule recomputed from the returned rows, the compare-count
     checksum, shard + merge == single sweep."""
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(77)
-    n, d, k, nq = 4_000_000, 3584, 100, 512
+    n, d, k, nq = 10_000_000, 3584, 100, 512
     c8 = torch.empty((n, d), dtype=torch.int8, device=dev)
     cs = torch.empty((n,), dtype=torch.float32, device=dev)
     for s in range(0, n, 1 << 18):
@@ -120,7 +120,7 @@ def test_int8_config_properties():
     kth = v[:, k - 1].contiguous()
     _, _, rank = kernels.topk(q8, c8, 1, q_scale=qs, c_scale=cs, rank_ref=kth)
     assert torch.equal(rank, (v > kth[:, None]).sum(dim=1).to(rank.dtype))
-    cut = 1_500_003
+    cut = 3_750_003
     pv0, pi0, _ = kernels.topk(q8, c8[:cut], k, q_scale=qs, c_scale=cs[:cut])
     pv1, pi1, _ = kernels.topk(q8, c8[cut:], k, q_scale=qs, c_scale=cs[cut:], idx_offset=cut)
     mv, mi = kernels.merge_topk(torch.stack([pv0, pv1]), torch.stack([pi0, pi1]))

@@ -54,10 +54,15 @@ __device__ __forceinline__ void compact_list_e(uint64_t* buf, int n, int k, int 
     kth = shfl_u64(kth, (k - 1) & 63);
     new_cnt = keep;
     new_thr = (n >= k) ? key_val(kth) : -INFINITY;
-    // every list of the query publishes its value at rank pub_m-1 (pub_m <= 64); with L lists and
-    // L*pub_m >= k the minimum over the lists is a lower bound of the query's global k-th best
-    const uint64_t mth = shfl_u64(key[0], (pub_m - 1) & 63);
-    pub_val = (n >= pub_m) ? key_val(mth) : -INFINITY;
+    // every list of the query publishes its value at rank pub_m-1 (selected like kth: pub_m > 64 happens with one list
+    // per query and k > 64); with L lists and L*pub_m >= k the minimum over the lists is a lower bound of the query's
+    // global k-th best
+    uint64_t mth = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e == ((pub_m - 1) >> 6)) mth = key[e];
+    mth = shfl_u64(mth, (pub_m - 1) & 63);
+    pub_val = (n >= pub_m && pub_m <= 64 * E) ? key_val(mth) : -INFINITY;
 }
 
 #include "sweep16.inc"

@@ -50,6 +50,18 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
     return ws
 
 
+def release_workspaces(device: Optional[torch.device] = None) -> int:
+    """Drop the cached scratch buffers (of one device, or all) and return the bytes released.  The cache holds one
+    buffer per (device, stream) that ever ran a search -- up to ~540 MB each at 8192-query launches -- and never shrinks
+    on its own: call this when a stream is retired, or between phases of a job that used many streams.  Work already
+    enqueued keeps its buffer alive (the caching allocator recycles it only after the stream has passed it)."""
+    freed = 0
+    for key in list(_workspaces):
+        if device is None or (key[0], key[1]) == (device.type, device.index if device.index is not None else key[1]):
+            freed += _workspaces.pop(key).numel()
+    return freed
+
+
 def topk(q: torch.Tensor, c: torch.Tensor, k: int, upper_bound: Optional[torch.Tensor] = None,
          idx_offset: int = 0, rank_ref: Optional[torch.Tensor] = None, rank_self_offset: Optional[int] = None,
          q_scale: Optional[torch.Tensor] = None, c_scale: Optional[torch.Tensor] = None
