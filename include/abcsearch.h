@@ -150,11 +150,12 @@ int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* stream);
  *   q [B,d] f32, p [C,d] f32 (C >= B; row i of p is the positive of query i)
  *   temp [1] f32 DEVICE scalar (Temperature.temp, model/modeling_abc.py:36-43; score = s / temp)
  *   out_loss [1] f32 (mean over rows), out_lse [B] f32 (logsumexp of score rows),
- *   out_argmax [B] i32, workspace >= abc_infonce_workspace_bytes(B,C,d)
+ *   out_argmax [B] i32, out_acc [1] f32 or NULL: accuracy = (argmax == arange(B)).sum() / B (abc_util.py:52-54),
+ *   workspace >= abc_infonce_workspace_bytes(B,C,d)
  */
 size_t abc_infonce_workspace_bytes(int B, int C, int d);
 int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
-                    float* out_loss, float* out_lse, int32_t* out_argmax,
+                    float* out_loss, float* out_lse, int32_t* out_argmax, float* out_acc,
                     void* workspace, size_t workspace_bytes, void* stream);
 /*
  * The forward for callers that cannot allocate.  No counterpart in the reference; it exists for callers that must
@@ -163,12 +164,18 @@ int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps
  * as `workspace` lives in a 16 MiB device array inside the library (one copy per GPU, held until the process ends).
  * Shapes whose abc_infonce_workspace_bytes exceeds abc_infonce_noalloc_max_bytes() are refused with ABC_E_WORKSPACE
  * (B=128 x C=8192, the 8-GPU form of BASELINE configs[3], needs 8.3 MiB).  Calls no hipMalloc / hipFree.
- * Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ * Every call on one GPU shares that GPU's array: calls on ONE stream run in order; a call on another stream while the
+ * previous call's stream still has work pending is refused with ABC_E_INVALID (it would race on the array; two host
+ * threads calling at the same moment are not detected: give the entry point one owner per GPU).
+ * The array used is the CURRENT device's: `stream` must belong to the current device, else ABC_E_INVALID.
+ * The first use on a device resolves the array's address (hipGetSymbolAddress: loads the code object, which may
+ * allocate and must not happen under stream capture): call abc_infonce_noalloc_max_bytes() once per device, with that
+ * device current, before capturing.
  * There is no backward for it: the logits stay in the library's array only until the next call.
  */
 size_t abc_infonce_noalloc_max_bytes(void);
 int abc_infonce_fwd_noalloc(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
-                            float* out_loss, float* out_lse, int32_t* out_argmax, void* stream);
+                            float* out_loss, float* out_lse, int32_t* out_argmax, float* out_acc, void* stream);
 
 /*
  * InfoNCE backward (closed form of the autograd of model/abc_util.py:47-51):

@@ -35,9 +35,9 @@ SIGNATURES = {
     "abc_quantize_i8": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "abc_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),
     "abc_infonce_workspace_bytes": (_sz, [_int, _int, _int]),
-    "abc_infonce_fwd": (_int, [_vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_infonce_fwd": (_int, [_vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "abc_infonce_noalloc_max_bytes": (_sz, []),
-    "abc_infonce_fwd_noalloc": (_int, [_vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "abc_infonce_fwd_noalloc": (_int, [_vp, _vp, _vp, _f32, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "abc_mean_pool_bf16": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _int, _vp, _vp]),
     "abc_mean_pool_f32": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp]),
     "abc_embed_head_workspace_bytes": (_sz, [_int, _int, _int]),

@@ -56,7 +56,7 @@ static NceLayout nce_layout(int B, int C, int d) {
     L.off_z = take((size_t)B * L.ldz * 4);
     L.off_part = take((size_t)sk * B * L.ldz * 4);
     L.off_stats = take((size_t)B * L.n_fct * NCE_STAT * 4);
-    L.off_rowloss = take((size_t)B * 4);
+    L.off_rowloss = take((size_t)B * 8);           // row losses, then the rows' accuracy flags
     L.off_rowdt = take((size_t)B * 4);
     L.off_cnt = take((size_t)L.n_cnt * 4);
     L.total = o;
@@ -100,7 +100,7 @@ struct NceFwdArgs {
     int B, C, d, ldz, n_frt, n_fct, splitk;
     float *z, *part, *stats, *row_loss;
     unsigned* cnt;                 // [tiles] split arrivals, [n_frt] tile arrivals per 64-row block, [1] row blocks, [1] d_temp (backward)
-    float *out_loss, *out_lse;
+    float *out_loss, *out_lse, *out_acc;
     int* out_argmax;
 };
 
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(512) void nce_fwd_kernel(const NceFwdArgs a) {
         // (1-eps)*(-logp_ii) + (eps/C)*sum_j(-logp_ij), logp = z - lse
         __hip_atomic_store(a.row_loss + grow, (1.f - a.eps) * (l - szii) + a.eps * (l - szs / (float)a.C), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);                                  // sc1 store: handed to the last row block
+        __hip_atomic_store(a.row_loss + a.B + grow, amx == grow ? 1.f : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     {   // sc1-form arrival of this one wave (its hand-off stores above are sc1; the loads below are sc1 loads)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -355,11 +356,18 @@ __global__ __launch_bounds__(512) void nce_fwd_kernel(const NceFwdArgs a) {
         if (__builtin_amdgcn_readfirstlane(ticket) != (unsigned)a.n_frt - 1) return;
     }
     // ---- last row block: mean loss, fixed order
-    float s = 0.f;
-    for (int i = lane; i < a.B; i += 64) s += __hip_atomic_load(a.row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float s = 0.f, hits = 0.f;
+    for (int i = lane; i < a.B; i += 64) {
+        s += __hip_atomic_load(a.row_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hits += __hip_atomic_load(a.row_loss + a.B + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) a.out_loss[0] = s * (1.0f / (float)a.B);
+    for (int m = 32; m > 0; m >>= 1) { s += __shfl_xor(s, m, 64); hits += __shfl_xor(hits, m, 64); }
+    if (lane == 0) {
+        a.out_loss[0] = s * (1.0f / (float)a.B);
+        // accuracy = (argmax == arange(bs)).sum() / bs (model/abc_util.py:52-54): an exact count, one fp32 division
+        if (a.out_acc) a.out_acc[0] = __fdiv_rn(hits, (float)a.B);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,7 +534,8 @@ static int nce_check(int B, int C, int d) {
 }
 
 static void nce_fwd_launch(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
-                           float* out_loss, float* out_lse, int32_t* out_argmax, char* w, const NceLayout& L, hipStream_t st) {
+                           float* out_loss, float* out_lse, int32_t* out_argmax, float* out_acc, char* w, const NceLayout& L,
+                           hipStream_t st) {
     NceFwdArgs a;
     a.q = q; a.p = p; a.temp = temp; a.eps = eps;
     a.B = B; a.C = C; a.d = d; a.ldz = L.ldz; a.n_frt = L.n_frt; a.n_fct = L.n_fct; a.splitk = L.splitk;
@@ -535,13 +544,13 @@ static void nce_fwd_launch(const float* q, const float* p, const float* temp, fl
     a.stats = (float*)(w + L.off_stats);
     a.row_loss = (float*)(w + L.off_rowloss);
     a.cnt = (unsigned*)(w + L.off_cnt);
-    a.out_loss = out_loss; a.out_lse = out_lse; a.out_argmax = out_argmax;
+    a.out_loss = out_loss; a.out_lse = out_lse; a.out_argmax = out_argmax; a.out_acc = out_acc;
     hipLaunchKernelGGL(nce_fwd_kernel, dim3(L.n_frt * L.n_fct, L.splitk), dim3(512), 65536, st, a);
 }
 
 extern "C" int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
-                               float* out_loss, float* out_lse, int32_t* out_argmax, void* ws, size_t ws_bytes,
-                               void* stream) {
+                               float* out_loss, float* out_lse, int32_t* out_argmax, float* out_acc, void* ws,
+                               size_t ws_bytes, void* stream) {
     int rc = nce_check(B, C, d);
     if (rc) return rc;
     if (!q || !p || !temp || !out_loss || !out_lse || !out_argmax) return abc_fail_invalid("infonce_fwd: null pointer");
@@ -555,7 +564,7 @@ extern "C" int abc_infonce_fwd(const float* q, const float* p, const float* temp
     // anything the first time; afterwards the last arriver leaves every counter at zero itself)
     hipError_t e = hipMemsetAsync(w + L.off_cnt, 0, (size_t)L.n_cnt * 4, st);
     if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd memset");
-    nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, w, L, st);
+    nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, out_acc, w, L, st);
     e = hipGetLastError();
     return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "infonce_fwd launch");
 }
@@ -570,12 +579,23 @@ extern "C" int abc_infonce_fwd(const float* q, const float* p, const float* temp
 #define NCE_MAX_DEVICES 64
 static __device__ __align__(256) unsigned char scratch[NCE_SCRATCH_BYTES];
 static std::atomic<void*> g_scratch_ptr[NCE_MAX_DEVICES];
+static std::atomic<hipStream_t> g_scratch_stream[NCE_MAX_DEVICES];      // the stream of the last call on each device
+static std::atomic<bool> g_scratch_used[NCE_MAX_DEVICES];
 
-static int nce_scratch(void** out) {
+// The scratch copy of the CURRENT device (each GPU has its own).  `stream`, when given, must belong to that device: the
+// kernel runs where the stream lives, and another GPU's scratch address is not valid there.
+static int nce_scratch(void** out, int* dev_out, hipStream_t stream, bool check_stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc hipGetDevice");
     if (dev < 0 || dev >= NCE_MAX_DEVICES) return abc_fail_invalid("infonce_fwd_noalloc: device index out of range");
+    if (check_stream && stream) {
+        int sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc hipStreamGetDevice");
+        if (sdev != dev) return abc_fail_invalid("infonce_fwd_noalloc: the stream belongs to another device than the current one");
+    }
+    if (dev_out) *dev_out = dev;
     void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
     if (!p) {                                   // first call on this device, with this device current
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
@@ -586,10 +606,16 @@ static int nce_scratch(void** out) {
     return ABC_OK;
 }
 
-extern "C" size_t abc_infonce_noalloc_max_bytes(void) { return NCE_SCRATCH_BYTES; }
+// Also the warm-up call: resolves the current device's scratch address (hipGetSymbolAddress loads the code object on
+// first use, which allocates), so that a later abc_infonce_fwd_noalloc on this device may run under stream capture.
+extern "C" size_t abc_infonce_noalloc_max_bytes(void) {
+    void* sp = nullptr;
+    (void)nce_scratch(&sp, nullptr, nullptr, false);
+    return NCE_SCRATCH_BYTES;
+}
 
 extern "C" int abc_infonce_fwd_noalloc(const float* q, const float* p, const float* temp, float eps, int B, int C, int d,
-                                       float* out_loss, float* out_lse, int32_t* out_argmax, void* stream) {
+                                       float* out_loss, float* out_lse, int32_t* out_argmax, float* out_acc, void* stream) {
     int rc = nce_check(B, C, d);
     if (rc) return rc;
     if (!q || !p || !temp || !out_loss || !out_lse || !out_argmax) return abc_fail_invalid("infonce_fwd_noalloc: null pointer");
@@ -597,15 +623,36 @@ extern "C" int abc_infonce_fwd_noalloc(const float* q, const float* p, const flo
     const NceLayout L = nce_layout(B, C, d);
     if (L.total > NCE_SCRATCH_BYTES) return abc_fail_ws(L.total, NCE_SCRATCH_BYTES);   // "workspace too small: need N bytes, have 16 MiB"
     void* sp = nullptr;
-    rc = nce_scratch(&sp);
-    if (rc) return rc;
+    int dev = 0;
     hipStream_t st = (hipStream_t)stream;
+    rc = nce_scratch(&sp, &dev, st, true);
+    if (rc) return rc;
+    // Calls on one GPU share its array.  Calls on ONE stream run in order; a call on another stream while the previous
+    // call's stream still has work pending would race with it on the array: refused instead of silently corrupting.
+    // (The query is made only when the stream changes, and never on the stream this call is for.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
+    // (a capturing stream launches nothing now; what its graph overlaps with at replay is the replaying caller's to order)
+    if (cap == hipStreamCaptureStatusNone && g_scratch_used[dev].load(std::memory_order_acquire)) {
+        const hipStream_t prev = g_scratch_stream[dev].load(std::memory_order_acquire);
+        if (prev != st) {
+            const hipError_t qe = hipStreamQuery(prev);
+            if (qe == hipErrorNotReady) {
+                (void)hipGetLastError();
+                return abc_fail_invalid("infonce_fwd_noalloc: the previous call on this GPU, on another stream, may still be running "
+                                        "(calls share one scratch array per GPU: use one stream, or synchronise between streams)");
+            }
+            if (qe != hipSuccess) (void)hipGetLastError();            // e.g. the earlier stream no longer exists
+        }
+    }
+    g_scratch_stream[dev].store(st, std::memory_order_release);
+    g_scratch_used[dev].store(true, std::memory_order_release);
     char* w = (char*)sp;
     // the array keeps the last call's contents: the counters must start at zero (a completed call leaves them at zero
     // itself; this covers a call that was abandoned half-way).  Everything else is written before it is read.
     hipError_t e = hipMemsetAsync(w + L.off_cnt, 0, (size_t)L.n_cnt * 4, st);
     if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc memset");
-    nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, w, L, st);
+    nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, out_acc, w, L, st);
     e = hipGetLastError();
     return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "infonce_fwd_noalloc launch");
 }
