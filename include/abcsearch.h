@@ -165,8 +165,8 @@ int abc_infonce_fwd(const float* q, const float* p, const float* temp, float eps
  * Shapes whose abc_infonce_workspace_bytes exceeds abc_infonce_noalloc_max_bytes() are refused with ABC_E_WORKSPACE
  * (B=128 x C=8192, the 8-GPU form of BASELINE configs[3], needs 8.3 MiB).  Calls no hipMalloc / hipFree.
  * Every call on one GPU shares that GPU's array: calls on ONE stream run in order; a call on another stream while the
- * previous call's stream still has work pending is refused with ABC_E_INVALID (it would race on the array; two host
- * threads calling at the same moment are not detected: give the entry point one owner per GPU).
+ * previous call has not finished (an event recorded behind every call) is refused with ABC_E_INVALID: it would race on
+ * the array.  Two host threads calling at the same moment are not detected: give the entry point one owner per GPU.
  * The array used is the CURRENT device's: `stream` must belong to the current device, else ABC_E_INVALID.
  * The first use on a device resolves the array's address (hipGetSymbolAddress: loads the code object, which may
  * allocate and must not happen under stream capture): call abc_infonce_noalloc_max_bytes() once per device, with that

@@ -581,6 +581,7 @@ static __device__ __align__(256) unsigned char scratch[NCE_SCRATCH_BYTES];
 static std::atomic<void*> g_scratch_ptr[NCE_MAX_DEVICES];
 static std::atomic<hipStream_t> g_scratch_stream[NCE_MAX_DEVICES];      // the stream of the last call on each device
 static std::atomic<bool> g_scratch_used[NCE_MAX_DEVICES];
+static std::atomic<hipEvent_t> g_scratch_event[NCE_MAX_DEVICES];       // recorded behind the last eager call
 
 // The scratch copy of the CURRENT device (each GPU has its own).  `stream`, when given, must belong to that device: the
 // kernel runs where the stream lives, and another GPU's scratch address is not valid there.
@@ -600,6 +601,9 @@ static int nce_scratch(void** out, int* dev_out, hipStream_t stream, bool check_
     if (!p) {                                   // first call on this device, with this device current
         e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess || !p) return abc_fail_hip(e, "infonce_fwd_noalloc hipGetSymbolAddress(scratch)");
+        hipEvent_t ev = nullptr;                 // the "last call has finished" marker of the in-use guard, once per device
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) g_scratch_event[dev].store(ev, std::memory_order_release);
+        else (void)hipGetLastError();
         g_scratch_ptr[dev].store(p, std::memory_order_release);
     }
     *out = p;
@@ -628,25 +632,23 @@ extern "C" int abc_infonce_fwd_noalloc(const float* q, const float* p, const flo
     rc = nce_scratch(&sp, &dev, st, true);
     if (rc) return rc;
     // Calls on one GPU share its array.  Calls on ONE stream run in order; a call on another stream while the previous
-    // call's stream still has work pending would race with it on the array: refused instead of silently corrupting.
-    // (The query is made only when the stream changes, and never on the stream this call is for.)
+    // call has not finished would race with it on the array: refused instead of silently corrupting.  "Finished" is
+    // an event recorded behind every call (created once per device at set-up; no allocation per call).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) { cap = hipStreamCaptureStatusNone; (void)hipGetLastError(); }
     // (a capturing stream launches nothing now; what its graph overlaps with at replay is the replaying caller's to order)
-    if (cap == hipStreamCaptureStatusNone && g_scratch_used[dev].load(std::memory_order_acquire)) {
-        const hipStream_t prev = g_scratch_stream[dev].load(std::memory_order_acquire);
-        if (prev != st) {
-            const hipError_t qe = hipStreamQuery(prev);
-            if (qe == hipErrorNotReady) {
-                (void)hipGetLastError();
-                return abc_fail_invalid("infonce_fwd_noalloc: the previous call on this GPU, on another stream, may still be running "
-                                        "(calls share one scratch array per GPU: use one stream, or synchronise between streams)");
-            }
-            if (qe != hipSuccess) (void)hipGetLastError();            // e.g. the earlier stream no longer exists
+    const bool eager = cap == hipStreamCaptureStatusNone;
+    hipEvent_t ev = g_scratch_event[dev].load(std::memory_order_acquire);
+    if (eager && ev && g_scratch_used[dev].load(std::memory_order_acquire) &&
+        g_scratch_stream[dev].load(std::memory_order_acquire) != st) {
+        const hipError_t qe = hipEventQuery(ev);
+        if (qe == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return abc_fail_invalid("infonce_fwd_noalloc: the previous call on this GPU, on another stream, has not finished "
+                                    "(calls share one scratch array per GPU: use one stream, or synchronise between streams)");
         }
+        if (qe != hipSuccess) (void)hipGetLastError();
     }
-    g_scratch_stream[dev].store(st, std::memory_order_release);
-    g_scratch_used[dev].store(true, std::memory_order_release);
     char* w = (char*)sp;
     // the array keeps the last call's contents: the counters must start at zero (a completed call leaves them at zero
     // itself; this covers a call that was abandoned half-way).  Everything else is written before it is read.
@@ -654,7 +656,14 @@ extern "C" int abc_infonce_fwd_noalloc(const float* q, const float* p, const flo
     if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc memset");
     nce_fwd_launch(q, p, temp, eps, B, C, d, out_loss, out_lse, out_argmax, out_acc, w, L, st);
     e = hipGetLastError();
-    return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "infonce_fwd_noalloc launch");
+    if (e != hipSuccess) return abc_fail_hip(e, "infonce_fwd_noalloc launch");
+    if (eager && ev) {
+        if (hipEventRecord(ev, st) == hipSuccess) {
+            g_scratch_stream[dev].store(st, std::memory_order_release);
+            g_scratch_used[dev].store(true, std::memory_order_release);
+        } else (void)hipGetLastError();
+    }
+    return ABC_OK;
 }
 
 extern "C" int abc_infonce_bwd(const float* q, const float* p, const float* lse, const float* temp, float eps,
