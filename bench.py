@@ -71,7 +71,13 @@ def main():
     ap.add_argument("--full-job", action="store_true",
                     help="time the WHOLE mining job (every corpus row is a query: 3.3M queries, about 70 s on one GPU) "
                          "instead of --steps batches of it; --steps is then derived from the corpus size")
+    ap.add_argument("--from-files", action="store_true",
+                    help="time the file-driven mining job (create_negative_index.py:30-43): synthetic query.pt / cand.pt "
+                         "(fp32, --nc rows, default 412 500) written to local disk -> negatives.json through "
+                         "vllm_amd.mining.create_negative_index, beside the rate of the same job with the queries resident in HBM")
     args = ap.parse_args()
+    if args.from_files:
+        return from_files_mode(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -223,6 +229,84 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def from_files_mode(args):
+    """One GPU.  The whole job of pretrain/create_negative_index.py:30-43 from the files the embedding pass leaves
+    (query.pt / cand.pt, fp32 [N, D]) to negatives.json, timed end to end and by phase, beside the same N queries mined
+    from HBM-resident bf16 embeddings (what the default bench line times per step).  PCIe and file reads are inside
+    the file-driven number; the files were written just before, so they come from the page cache, not the disk."""
+    import shutil
+    import tempfile
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--from-files is a one-GPU measurement")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    from vllm_amd import search, mining
+    nc = args.nc if args.nc != NC_FULL else 412_500
+    seed = 1234
+    mu = centres(dev, seed)
+    root = tempfile.mkdtemp(prefix="abc_mining_", dir=os.environ.get("ABC_BENCH_TMP", tempfile.gettempdir()))
+    try:
+        neg = os.path.join(root, "negative")
+        os.makedirs(neg)
+        t0 = time.perf_counter()
+        for name, want_q in (("cand.pt", False), ("query.pt", True)):
+            host = torch.empty((nc, D), dtype=torch.float32)
+            for lo in range(0, nc, CHUNK):
+                hi = min(nc, lo + CHUNK)
+                host[lo:hi] = gen_rows(lo, hi, mu, seed, want_q).float().cpu()
+            torch.save(host, os.path.join(neg, name))
+            del host
+        t_write = time.perf_counter() - t0
+
+        # (a) queries resident in HBM: the per-step path of the default bench line over all nc queries
+        c_res = search.Embeddings(gen_rows(0, nc, mu, seed, want_q=False), "bf16", dev)
+        q_res = search.Embeddings(gen_rows(0, nc, mu, seed, want_q=True), "bf16", dev)
+        bq = QUERIES_PER_GPU_STEP
+        search.mine_negatives(q_res.rows(0, bq), c_res, K, offset=0)              # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        keep = []
+        for s in range(0, nc, bq):
+            keep.append(search.mine_negatives(q_res.rows(s, min(nc, s + bq)), c_res, K, offset=s)[0])
+        torch.cuda.synchronize()
+        t_res = time.perf_counter() - t0
+        ref_idx = torch.cat(keep).cpu()
+        del keep, c_res, q_res
+        torch.cuda.empty_cache()
+
+        # (b) from the files
+        timings = {}
+        t0 = time.perf_counter()
+        out = mining.create_negative_index(neg, top=K, compute="bf16", block=bq, resume=False, timings=timings)
+        t_files = time.perf_counter() - t0
+        size = os.path.getsize(out)
+        # same lists as the resident run (spot check: first, last and a stride of rows)
+        with open(out, "rb") as f:
+            got = json.loads(f.read())
+        rows = sorted(set(list(range(0, nc, max(nc // 997, 1))) + [nc - 1]))
+        same = all(got[str(r)] == [j for j in ref_idx[r].tolist() if j >= 0] for r in rows)
+        if len(got) != nc or not same:
+            raise SystemExit("bench.py --from-files: negatives.json differs from the resident-query run")
+        loop_rate = nc / timings["loop"]
+        result = {
+            "metric": "queries/sec exact top-64 hard-negative mining, query.pt/cand.pt -> negatives.json",
+            "value": nc / t_files, "unit": "queries/s", "n_gpus": 1, "steps": (nc + bq - 1) // bq, "warmup": 1,
+            "ms_per_step": t_files / ((nc + bq - 1) // bq) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"create_negative_index from files: {nc} x {D} fp32 query.pt + cand.pt -> bf16 search, k={K}, "
+                                   f"0.95-positive rule, blocks of {bq} -> negatives.json ({size / 1e6:.0f} MB)",
+                       "corpus_rows": nc, "d": D, "k": K},
+            "from_files": {"total_s": t_files, "phases_s": timings, "loop_queries_per_s": loop_rate,
+                           "resident_queries_per_s": nc / t_res, "loop_vs_resident": loop_rate / (nc / t_res),
+                           "total_vs_resident": (nc / t_files) / (nc / t_res),
+                           "files_written_s": t_write, "page_cache": "files written just before the run: reads come from the page cache",
+                           "check": f"negatives.json == resident-query lists on {len(rows)} sampled rows, {len(got)} rows in all"},
+        }
+        print(json.dumps(result), flush=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def sweep_kernel_name(rows):

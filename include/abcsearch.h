@@ -217,6 +217,15 @@ int abc_embed_head_f32(const float* x, const float* w1, const float* b1, const f
                        int B, int H, int Hd, int normalize, float* out_f32, void* out_bf16, int8_t* out_i8,
                        float* out_scale, void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * negatives.json text, host code (no GPU, no stream).  Replaces the serialisation half of
+ * pretrain/create_negative_index.py:40-43 (json.dump(negative_dict, f) over {int idx: [100 ints]}): the bytes json.dump
+ * writes for rows first_row .. first_row + n_rows - 1 -- `"17": [3, 5, 8]` entries joined by ", ", keys as strings, no
+ * braces (the caller writes "{", "}" and the ", " between blocks).  idx [n_rows, k] i64 HOST memory, entries < 0 dropped.
+ * Returns the byte count written to out[0 .. cap), or -(bytes needed) when cap is too small (nothing written).
+ */
+int64_t abc_format_negatives(const int64_t* idx, int64_t n_rows, int k, int64_t first_row, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,33 @@ def test_driver_resume_bookkeeping(tmp_path, monkeypatch):
         idx = torch.tensor([nd[offset + i] for i in range(qb.shape[0])])
         return idx, None, None
 
+    class FakeStage:                               # mining._StagedRows without a GPU: the block as it is
+        def __init__(self, x, block, compute, device):
+            self.x, self.nxt = x, None
+
+        def prefetch(self, lo, hi):
+            assert self.nxt is None
+            self.nxt = (lo, hi)
+
+        def take(self):
+            (lo, hi), self.nxt = self.nxt, None
+            return _CpuEmb(self.x[lo:hi])
+
+        def close(self):
+            pass
+
+    class FakeDownload:                            # mining._Download without a GPU
+        def __init__(self, block, top, device):
+            pass
+
+        def start(self, slot, idx):
+            return idx
+
+        def wait(self, handle):
+            return handle.numpy(), bool((handle[:, -1] < 0).any())
+
+    monkeypatch.setattr(mining, "_StagedRows", FakeStage)
+    monkeypatch.setattr(mining, "_Download", FakeDownload)
     monkeypatch.setattr(mining, "upload", lambda x, compute, rows=None, **kw: _CpuEmb(x[rows[0]:rows[1]]))
     monkeypatch.setattr(mining.search, "Embeddings", lambda x, compute, dev=None: _CpuEmb(x))
     monkeypatch.setattr(mining.parallel.ShardedCorpus, "mine_negatives",
@@ -106,8 +133,11 @@ def test_driver_resume_bookkeeping(tmp_path, monkeypatch):
 
     with pytest.raises(Crash):
         mining.create_negative_index(d, top=100, block=64, progress=crash_after_two)
-    assert calls == [0, 64]
-    assert not os.path.exists(os.path.join(d, "negatives.json"))
+    # the driver is one block ahead of what it has written: block 128 was searched, blocks 0 and 64 are on disk
+    assert calls == [0, 64, 128]
+    assert sorted(f for f in os.listdir(os.path.join(d, mining.PARTS_DIR)) if f.endswith(".npy")) == \
+        ["part-000000000000.npy", "part-000000000064.npy"]
+    assert not os.path.exists(os.path.join(d, "negatives.json")) and not os.path.exists(os.path.join(d, "negatives.json.tmp"))
     # torn file from the crash window must be redone, finished blocks are kept
     open(os.path.join(d, mining.PARTS_DIR, "part-000000000128.npy"), "wb").write(b"\x93NUMPY garbage")
     calls.clear()

@@ -31,6 +31,7 @@ SIGNATURES = {
     "abc_topk_packed": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _i64, _int, _int, _vp, _i64, _vp, _vp, _sz, _vp]),
     "abc_topk_merge_packed": (_int, [_vp, _int, _i64, _int, _vp, _vp, _vp]),
     "abc_debug_set": (_int, [C.c_char_p, _i64]),
+    "abc_format_negatives": (_i64, [_vp, _i64, _int, _i64, _vp, _i64]),
     "abc_debug_get": (_i64, [C.c_char_p]),
     "abc_quantize_i8": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "abc_cast_bf16": (_int, [_vp, _i64, _vp, _vp]),

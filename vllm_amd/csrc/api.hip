@@ -271,3 +271,42 @@ extern "C" int abc_cast_bf16(const float* x, int64_t n, void* out_bf16, void* st
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "cast launch");
 }
+
+// ------------------------------------------------------------------------------------------------
+// negatives.json text (host code, no GPU): the bytes json.dump(negative_dict, f) writes for rows first_row ..
+// first_row + n_rows - 1 of the {int: [int, ...]} dict of pretrain/create_negative_index.py:34-43 -- keys as
+// strings, ", " between entries and between items, no braces (the caller writes "{" / "}" and the ", " between blocks).
+// Entries < 0 (no candidate) are dropped.  Returns the byte count, or -(bytes needed) when `cap` is too small.
+static inline char* put_i64(char* p, int64_t v) {
+    char tmp[24];
+    int n = 0;
+    uint64_t u = v < 0 ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *p++ = '-';
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+extern "C" int64_t abc_format_negatives(const int64_t* idx, int64_t n_rows, int k, int64_t first_row, char* out, int64_t cap) {
+    if (!idx || n_rows < 0 || k < 0) { fail(ABC_E_INVALID, "abc_format_negatives: bad arguments"); return 0; }
+    // worst case per row: '"' + 20 digits + '": [' + k * (20 digits + ", ") + "]" + ", "
+    const int64_t worst = n_rows * (28 + (int64_t)k * 22 + 3);
+    if (!out || cap < worst) return -worst;
+    char* p = out;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        if (r) { *p++ = ','; *p++ = ' '; }
+        *p++ = '"';
+        p = put_i64(p, first_row + r);
+        *p++ = '"'; *p++ = ':'; *p++ = ' '; *p++ = '[';
+        bool first = true;
+        const int64_t* row = idx + r * k;
+        for (int j = 0; j < k; ++j) {
+            if (row[j] < 0) continue;
+            if (!first) { *p++ = ','; *p++ = ' '; }
+            p = put_i64(p, row[j]);
+            first = false;
+        }
+        *p++ = ']';
+    }
+    return (int64_t)(p - out);
+}

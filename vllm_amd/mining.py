@@ -18,16 +18,19 @@ No CPU path: the search runs in libabcsearch.so on the GPU (vllm_amd.search / vl
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import os
 import sys
+import time as _time
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import parallel, search
+from . import _lib, parallel, search
 from ._lib import AbcError
 
 PARTS_DIR = "negatives.parts"
@@ -64,59 +67,190 @@ def load_embeddings(negative_path: str) -> Tuple[torch.Tensor, torch.Tensor]:
     return q, c
 
 
+class _StagedRows:
+    """Row blocks of a (possibly memory-mapped) CPU table on their way to the GPU: the copy out of the mapping (page-ins
+    included) into one of two pinned staging buffers runs on worker threads, a slice each, the host-to-device copy and the
+    conversion to the compute dtype on a side stream -- while the caller's stream works on the block before.
+
+        st = _StagedRows(x, block, compute, device); st.prefetch(lo, hi); emb = st.take()      # strictly alternating
+    """
+
+    def __init__(self, x: torch.Tensor, block: int, compute: str, device: torch.device, workers: int = 8):
+        self.x, self.block, self.compute, self.device = x, block, compute, device
+        self.pinned = [torch.empty((block, x.shape[1]), dtype=x.dtype).pin_memory() for _ in range(2)]
+        self.free_at = [None, None]                   # event: the slot's last host-to-device copy has run
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.workers = workers
+        self.side = torch.cuda.Stream(device)
+        self.slot = 0
+        self.pending = None
+        self.waited = 0.0                             # seconds the caller spent waiting for page-ins (diagnostics)
+
+    def prefetch(self, lo: int, hi: int) -> None:
+        assert self.pending is None and 0 < hi - lo <= self.block
+        slot, m = self.slot, hi - lo
+        if self.free_at[slot] is not None:
+            self.free_at[slot].synchronize()          # two blocks back: long done
+        buf = self.pinned[slot]
+        step = -(-m // self.workers)
+        futs = [self.pool.submit(buf[a:min(a + step, m)].copy_, self.x[lo + a:lo + min(a + step, m)])
+                for a in range(0, m, step)]
+        self.pending = (slot, m, futs)
+        self.slot ^= 1
+
+    def take(self) -> search.Embeddings:
+        """The prefetched block as resident Embeddings, usable on the CURRENT stream."""
+        slot, m, futs = self.pending
+        self.pending = None
+        t0 = _time.perf_counter()
+        for f in futs:
+            f.result()
+        self.waited += _time.perf_counter() - t0
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.side):
+            raw = self.pinned[slot][:m].to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.free_at[slot] = ev
+            emb = search.Embeddings(raw, self.compute, self.device)
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        cur.wait_event(ready)
+        for t in (raw, emb.data, emb.scale):          # allocated on the side stream, used on the caller's
+            if t is not None:
+                t.record_stream(cur)
+        return emb
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+
+
+class _Download:
+    """A block's result on its way back: the [m, top] index table and the "some row has fewer than top survivors" flag go
+    to one of two pinned host buffers with asynchronous copies; wait() blocks until they have arrived (by then the
+    next block's sweep is running)."""
+
+    def __init__(self, block: int, top: int, device: torch.device):
+        self.device = device
+        self.waited = 0.0                             # seconds spent waiting for the GPU (diagnostics)
+        self.host = [(torch.empty((block, top), dtype=torch.int64).pin_memory(), torch.empty((), dtype=torch.bool).pin_memory())
+                     for _ in range(2)]
+
+    def start(self, slot: int, idx: torch.Tensor):
+        arr_t, holes = self.host[slot]
+        arr_t[:idx.shape[0]].copy_(idx, non_blocking=True)
+        holes.copy_((idx[:, -1] < 0).any(), non_blocking=True)       # holes sit at the tail of a row
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return slot, idx.shape[0], ev
+
+    def wait(self, handle) -> Tuple[np.ndarray, bool]:
+        slot, m, ev = handle
+        t0 = _time.perf_counter()
+        ev.synchronize()
+        self.waited += _time.perf_counter() - t0
+        arr_t, holes = self.host[slot]
+        return arr_t[:m].numpy(), bool(holes)
+
+    def refresh(self, handle, idx: torch.Tensor) -> np.ndarray:
+        """After a tail fill changed idx on the device: fetch it again (synchronous; rare)."""
+        slot, m, _ = handle
+        arr_t, _ = self.host[slot]
+        arr_t[:m].copy_(idx)
+        return arr_t[:m].numpy()
+
+
 def upload(x: torch.Tensor, compute: str, device=None, rows: Optional[Tuple[int, int]] = None,
            block: int = 1 << 16) -> search.Embeddings:
     """Rows [lo, hi) of a (possibly memory-mapped) CPU table as resident Embeddings, converted block by
-    block so that neither the host nor the device ever holds a second full-size copy."""
+    block so that neither the host nor the device ever holds a second full-size copy; block i+1 is paged in and
+    copied while block i converts (_StagedRows)."""
     lo, hi = rows if rows is not None else (0, x.shape[0])
-    first = search.Embeddings(x[lo:min(lo + block, hi)], compute, device)
-    if hi - lo <= block:
-        return first
+    dev = search._device(device)
+    if hi - lo <= block or not x.device.type == "cpu":
+        return search.Embeddings(x[lo:hi], compute, dev)
+    st = _StagedRows(x, block, compute, dev)
     out = object.__new__(search.Embeddings)
     out.compute = compute
-    out.data = torch.empty((hi - lo, x.shape[1]), dtype=first.data.dtype, device=first.data.device)
-    out.scale = None if first.scale is None else torch.empty((hi - lo,), dtype=torch.float32, device=first.data.device)
-    pos = 0
-    part = first
-    while True:
-        n = part.data.shape[0]
-        out.data[pos:pos + n] = part.data
-        if out.scale is not None:
-            out.scale[pos:pos + n] = part.scale
-        pos += n
-        if lo + pos >= hi:
-            break
-        part = search.Embeddings(x[lo + pos:min(lo + pos + block, hi)], compute, first.data.device)
+    out.data = out.scale = None
+    pos = lo
+    st.prefetch(pos, min(pos + block, hi))
+    try:
+        while pos < hi:
+            n = min(block, hi - pos)
+            part = st.take()
+            if pos + n < hi:
+                st.prefetch(pos + n, min(pos + n + block, hi))
+            if out.data is None:
+                out.data = torch.empty((hi - lo, x.shape[1]), dtype=part.data.dtype, device=dev)
+                out.scale = None if part.scale is None else torch.empty((hi - lo,), dtype=torch.float32, device=dev)
+            out.data[pos - lo:pos - lo + n] = part.data
+            if out.scale is not None:
+                out.scale[pos - lo:pos - lo + n] = part.scale
+            pos += n
+    finally:
+        st.close()
     return out
 
 
-def _row_text(i: int, row: Sequence[int]) -> str:
-    return f'"{i}": [' + ", ".join(str(int(j)) for j in row) + "]"
+def format_negatives(first_row: int, arr: np.ndarray) -> bytes:
+    """The bytes json.dump writes for rows first_row.. of the {int: [ints]} dict (no braces), entries < 0 dropped:
+    abc_format_negatives, host code in the library (a Python loop over 3.3 M x 100 integers takes minutes)."""
+    lib = _lib.load()
+    a = np.ascontiguousarray(arr, dtype=np.int64)
+    n, k = (a.shape[0], a.shape[1]) if a.ndim == 2 else (0, 0)
+    if n == 0:
+        return b""
+    cap = -int(lib.abc_format_negatives(a.ctypes.data, n, k, int(first_row), None, 0))
+    buf = ctypes.create_string_buffer(cap)
+    got = int(lib.abc_format_negatives(a.ctypes.data, n, k, int(first_row), ctypes.addressof(buf), cap))
+    if got <= 0:
+        raise AbcError(f"abc_format_negatives failed ({got})")
+    return buf.raw[:got]
+
+
+class _JsonStream:
+    """negatives.json written block by block (tmp file, renamed by close()): "{" + blocks joined by ", " + "}"."""
+
+    def __init__(self, path: str):
+        self.path, self.tmp = path, path + ".tmp"
+        self.f = open(self.tmp, "wb")
+        self.f.write(b"{")
+        self.rows, self.first = 0, True
+
+    def add(self, start: int, arr: np.ndarray) -> None:
+        if start != self.rows:
+            raise AbcError(f"negatives blocks out of order: expected row {self.rows}, got {start}")
+        text = format_negatives(start, arr)
+        if text:
+            self.f.write((b"" if self.first else b", ") + text)
+            self.first = False
+        self.rows += arr.shape[0]
+
+    def close(self) -> int:
+        self.f.write(b"}")
+        self.f.close()
+        os.replace(self.tmp, self.path)
+        return self.rows
+
+    def abort(self) -> None:
+        self.f.close()
+        if os.path.exists(self.tmp):
+            os.remove(self.tmp)
 
 
 def write_negatives_json(path: str, blocks: Iterator[Tuple[int, np.ndarray]]) -> int:
     """Stream {"0": [..], "1": [..], ...} to `path` (tmp + rename).  `blocks` yields (first row, int array
     [n, k]) in row order; entries < 0 (no candidate) are dropped.  Byte-identical to json.dump of the
     reference's {int: list} dict."""
-    tmp = path + ".tmp"
-    n_rows = 0
-    with open(tmp, "w") as f:
-        f.write("{")
-        first = True
+    js = _JsonStream(path)
+    try:
         for start, arr in blocks:
-            if start != n_rows:
-                raise AbcError(f"negatives blocks out of order: expected row {n_rows}, got {start}")
-            lines = []
-            for r in range(arr.shape[0]):
-                row = arr[r]
-                lines.append(_row_text(start + r, row[row >= 0]))
-            if lines:
-                f.write(("" if first else ", ") + ", ".join(lines))
-                first = False
-            n_rows += arr.shape[0]
-        f.write("}")
-    os.replace(tmp, path)
-    return n_rows
+            js.add(start, arr)
+    except BaseException:
+        js.abort()
+        raise
+    return js.close()
 
 
 def load_negatives(path: str) -> Dict[str, List[int]]:
@@ -182,13 +316,28 @@ def _finished_blocks(parts_dir: str, starts: Sequence[int], sizes: Sequence[int]
 
 def create_negative_index(negative_path: str, top: int = 100, ratio: float = 0.95, compute: str = "f32",
                           block: int = 8192, resume: bool = True, keep_parts: bool = False,
-                          progress=None) -> str:
+                          progress=None, timings: Optional[dict] = None) -> str:
     """create_negative_index.main() for a directory holding query.pt / cand.pt; returns the path of
     negatives.json.  Under torch.distributed (one process per GPU) the corpus is row-sharded over the
-    ranks, every rank takes part in every block and rank 0 writes the files."""
+    ranks, every rank takes part in every block and rank 0 writes the files.
+
+    The loop is a software pipeline: while block t sweeps, block t+1 is paged in from query.pt, copied and converted on a
+    side stream, and block t-1's lists come back through pinned memory, go to their part file and are appended to
+    negatives.json (formatted by the library's host code), so the GPU never waits for the files.  `timings`, when given,
+    receives the seconds spent in {"load", "upload", "loop", "finalize"}."""
+    _t = [_time.perf_counter()]
+
+    def _lap(name: str) -> None:
+        if timings is not None:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            now = _time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + now - _t[0]
+            _t[0] = now
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     q_cpu, c_cpu = load_embeddings(negative_path)
+    _lap("load")
     n, d = q_cpu.shape
     top_eff = min(top, n)
     parts_dir = os.path.join(negative_path, PARTS_DIR)
@@ -215,37 +364,89 @@ def create_negative_index(negative_path: str, top: int = 100, ratio: float = 0.9
         done_starts = set(done)
 
     todo = [(s, m) for s, m in zip(starts, sizes) if s not in done_starts]
-    if todo:
-        lo, hi = parallel.shard_bounds(n, world, rank)
-        shard = upload(c_cpu, compute, rows=(lo, hi))
-        corpus = parallel.ShardedCorpus(shard, lo, n)
-        for s, m in todo:
-            qb = search.Embeddings(q_cpu[s:s + m], compute, shard.data.device)
-            # one code path at every world size (world 1: no collective, the local sweep is the result)
-            idx, _, _ = corpus.mine_negatives(qb, top_eff, ratio=ratio, offset=s)
-            if rank == 0:
-                arr = idx.to(torch.int64).cpu().numpy()
-                tmp = os.path.join(parts_dir, _part_name(s) + ".tmp")
-                with open(tmp, "wb") as f:
-                    np.save(f, arr, allow_pickle=False)
-                os.replace(tmp, os.path.join(parts_dir, _part_name(s)))
-            if progress is not None:
-                progress(s + m, n)
+    js = _JsonStream(out_path) if rank == 0 else None
+    next_json = 0                                       # index into `starts` of the next block negatives.json needs
+
+    def drain_json(upto: int) -> None:
+        """Append every finished block before starts[upto] to negatives.json, in row order (blocks found on disk from
+        an earlier run are formatted as they are reached)."""
+        nonlocal next_json
+        while js is not None and next_json < upto:
+            s0 = starts[next_json]
+            js.add(s0, np.load(os.path.join(parts_dir, _part_name(s0)), allow_pickle=False))
+            next_json += 1
+
+    try:
+        if todo:
+            lo, hi = parallel.shard_bounds(n, world, rank)
+            _lap("load")
+            shard = upload(c_cpu, compute, rows=(lo, hi))
+            _lap("upload")
+            dev = shard.data.device
+            corpus = parallel.ShardedCorpus(shard, lo, n)
+            stage = _StagedRows(q_cpu, block, compute, dev)
+            down = _Download(block, top_eff, dev)
+            inflight = None                             # (start, rows, download handle, query block, upper bounds, idx on device)
+
+            def finish(job) -> None:
+                """Block `job` has left the GPU: fill rows with fewer than `top` survivors (rare; a second search, the
+                same collectives on every rank), write the part file, extend negatives.json."""
+                s0, m0, handle, qb0, ub0, idx0 = job
+                arr, holes = down.wait(handle)
+                if holes:
+                    if world > 1:
+                        search.fill_masked_tail_rows(idx0, ub0, lambda rows: corpus.topk(qb0.take(rows), top_eff))
+                    else:
+                        search.fill_masked_tail_rows(idx0, ub0, lambda rows: search.topk(qb0.take(rows), shard, top_eff,
+                                                                                          idx_offset=lo)[:2])
+                    arr = down.refresh(handle, idx0)
+                if rank == 0:
+                    tmp = os.path.join(parts_dir, _part_name(s0) + ".tmp")
+                    with open(tmp, "wb") as f:
+                        np.save(f, arr, allow_pickle=False)
+                    os.replace(tmp, os.path.join(parts_dir, _part_name(s0)))
+                    drain_json(starts.index(s0) + 1)
+                if progress is not None:
+                    progress(s0 + m0, n)
+
+            stage.prefetch(todo[0][0], todo[0][0] + todo[0][1])
+            try:
+                for t, (s, m) in enumerate(todo):
+                    qb = stage.take()                   # block t on the device (its upload ran behind block t-1's sweep)
+                    if t + 1 < len(todo):
+                        stage.prefetch(todo[t + 1][0], todo[t + 1][0] + todo[t + 1][1])
+                    # one code path at every world size (world 1: no collective, the local sweep is the result)
+                    idx, _, s_pos = corpus.mine_negatives(qb, top_eff, ratio=ratio, offset=s, fill_masked_tail=False)
+                    handle = down.start(t & 1, idx)
+                    if inflight is not None:            # block t-1: written out while block t sweeps
+                        finish(inflight)
+                    inflight = (s, m, handle, qb, None if s_pos is None else s_pos * ratio, idx)
+                if inflight is not None:
+                    finish(inflight)
+            finally:
+                stage.close()
+            _lap("loop")
+            if timings is not None:
+                timings["loop_wait_pagein"] = getattr(stage, "waited", 0.0)
+                timings["loop_wait_gpu"] = getattr(down, "waited", 0.0)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            drain_json(len(starts))
+            rows = js.close()
+            js = None
+            if rows != n:
+                raise AbcError(f"negatives.json holds {rows} rows, expected {n}")
+            if not keep_parts:
+                for name in os.listdir(parts_dir):
+                    os.remove(os.path.join(parts_dir, name))
+                os.rmdir(parts_dir)
+    finally:
+        if js is not None:
+            js.abort()
     if world > 1:
         dist.barrier()
-    if rank == 0:
-        def blocks():
-            for s in starts:
-                yield s, np.load(os.path.join(parts_dir, _part_name(s)), allow_pickle=False)
-        rows = write_negatives_json(out_path, blocks())
-        if rows != n:
-            raise AbcError(f"negatives.json holds {rows} rows, expected {n}")
-        if not keep_parts:
-            for name in os.listdir(parts_dir):
-                os.remove(os.path.join(parts_dir, name))
-            os.rmdir(parts_dir)
-    if world > 1:
-        dist.barrier()
+    _lap("finalize")
     return out_path
 
 
