@@ -215,7 +215,28 @@ int abc_mean_pool_f32(const void* hidden, const int64_t* ids, int64_t pad_id, co
 size_t abc_embed_head_workspace_bytes(int B, int H, int Hd);
 int abc_embed_head_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                        int B, int H, int Hd, int normalize, float* out_f32, void* out_bf16, int8_t* out_i8,
-                       float* out_scale, void* workspace, size_t workspace_bytes, void* stream);
+                       float* out_scale, float* out_h1, float* out_norm, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/*
+ * out_h1 [B,Hd] and out_norm [B] (both nullable) are what the backward needs from the forward: selu(W1 x + b1) and ||y||_2.
+ *
+ * Backward of the head and of the mean pool: what autograd runs behind model/modeling_abc.py:148-154 in every training
+ * step (mean-pool -> mlp_head -> .float() -> F.normalize), between the loss's d emb (abc_infonce_bwd) and the backbone.
+ *   dy = (g - out (out . g)) / ||y||  (g / 1e-12 where the clamp is active; g when normalize = 0)
+ *   dW2 = dy^T h1, db2 = colsum(dy), da1 = (dy W2) * selu'(a1), dW1 = da1^T x, db1 = colsum(da1), dx = dy + da1 W1
+ *   grad_out, out [B,H], norm [B], x [B,H], h1 [B,Hd] f32 (out, h1, norm as abc_embed_head_f32 returned them);
+ *   dx [B,H], dw1 [Hd,H], db1 [Hd], dw2 [H,Hd], db2 [H]: each nullable (not computed); fp32, overwritten (not accumulated).
+ *   d hidden[b,s,:] = ((dx[b,:] / S) * [ids[b,s] != pad]) * instr[b,s], every position written, in hidden's dtype.
+ */
+size_t abc_embed_head_bwd_workspace_bytes(int B, int H, int Hd);
+int abc_embed_head_bwd(const float* grad_out, const float* out, const float* norm, const float* x, const float* h1,
+                       const float* w1, const float* w2, int B, int H, int Hd, int normalize,
+                       float* dx, float* dw1, float* db1, float* dw2, float* db2,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int abc_mean_pool_bwd_bf16(const float* dx, const int64_t* ids, int64_t pad_id, const float* instr, int B, int S, int H,
+                           void* dhidden, void* stream);
+int abc_mean_pool_bwd_f32(const float* dx, const int64_t* ids, int64_t pad_id, const float* instr, int B, int S, int H,
+                          float* dhidden, void* stream);
 
 /*
  * negatives.json text, host code (no GPU, no stream).  Replaces the serialisation half of

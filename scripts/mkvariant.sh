@@ -7,7 +7,7 @@ name=$1; extra=$2; dts=${3:-bf16}
 cd "$(dirname "$0")/../vllm_amd/csrc"
 mkdir -p build_v ../../variants
 objs=""
-for s in api topk_sweep sweep_inst_bf16 sweep_inst_i8 sweep_inst_f32 infonce embed_head; do
+for s in api topk_sweep sweep_inst_bf16 sweep_inst_i8 sweep_inst_f32 infonce embed_head embed_head_bwd; do
   dt=${s#sweep_inst_}
   if [[ $s == sweep_inst_* && " $dts " == *" $dt "* ]]; then
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=200000 $extra -c $s.hip -o build_v/${name}_$s.o

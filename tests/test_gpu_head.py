@@ -111,12 +111,138 @@ def test_identity_initialised_head_and_pipeline():
     assert i.flatten().tolist() == list(range(B))                     # every vector's nearest neighbour is itself
 
 
-def test_head_refuses_training_and_cpu():
+def test_head_refuses_cpu_and_quantised_outputs_under_grad():
     mlp = head.MLP(64, 64).to(DEV)
     x = torch.randn(4, 64, device=DEV)
     with pytest.raises(AbcError):
-        mlp(x)                                                        # grad enabled, parameters require grad
+        head._head(mlp, x, normalize=True, want_bf16=True)            # grad enabled: the corpus forms are inference outputs
     with torch.no_grad(), pytest.raises(AbcError):
         mlp(x.cpu())
     with torch.no_grad(), pytest.raises(AbcError):
         head.get_mean_token_embed(torch.zeros(2, 3, dtype=torch.long), torch.zeros(2, 3, 8), 0)
+
+
+def _trained_pair(H, Hd, g):
+    ref_mlp = oracle.OracleMLP(H, Hd)
+    with torch.no_grad():
+        for p in ref_mlp.parameters():
+            p.add_(0.02 * torch.randn(p.shape, generator=g))
+    mlp = head.MLP(H, Hd)
+    mlp.load_state_dict(ref_mlp.state_dict())
+    return ref_mlp, mlp.to(DEV)
+
+
+def _judge(got, ref32, ref64, what):
+    """The HIP gradient must be as close to the fp64 autograd result as torch-CPU fp32 autograd is (x4), or within 2e-6 of
+    the gradient's scale (cancellation in the normalise backward makes element-wise rtol between two fp32 results
+    meaningless, as for the loss: DESIGN.md section 2)."""
+    scale = float(ref64.abs().max())
+    e_got = float((got.double() - ref64).abs().max())
+    e_ref = float((ref32.double() - ref64).abs().max())
+    assert e_got <= max(4 * e_ref, 2e-6 * scale), (what, e_got, e_ref, scale)
+
+
+@pytest.mark.parametrize("B,H,Hd,normalize", [(288, 3584, 3584, True), (37, 896, 1024, True), (5, 64, 72, True), (16, 128, 128, False)])
+def test_head_backward_vs_autograd(B, H, Hd, normalize):
+    """d(normalize(mlp_head(x))) for x and the four parameters against torch-CPU autograd of the oracle's restatement of
+    model/modeling_abc.py:16-34,151-154 (fp32 and, as the judge, fp64).  288 x 3584 is one rank's 32 queries + 256
+    candidates of config/qwen/QwenVL-8B.json."""
+    g = torch.Generator().manual_seed(B + H)
+    ref_mlp, mlp = _trained_pair(H, Hd, g)
+    x = 0.5 * torch.randn(B, H, generator=g)
+    gout = torch.randn(B, H, generator=g) / H ** 0.5
+
+    def run_ref(dtype):
+        m = oracle.OracleMLP(H, Hd).to(dtype)
+        m.load_state_dict({k: v.to(dtype) for k, v in ref_mlp.state_dict().items()})
+        xx = x.detach().clone().to(dtype).requires_grad_(True)
+        y = m(xx)
+        out = torch.nn.functional.normalize(y, dim=-1) if normalize else y
+        out.backward(gout.to(dtype))
+        return [xx.grad, m.linear_layer1.weight.grad, m.linear_layer1.bias.grad, m.linear_layer2.weight.grad,
+                m.linear_layer2.bias.grad]
+
+    r32, r64 = run_ref(torch.float32), run_ref(torch.float64)
+    xd = x.detach().clone().to(DEV).requires_grad_(True)
+    out = head._head(mlp, xd, normalize=normalize)[0]
+    out.backward(gout.to(DEV))
+    got = [xd.grad, mlp.linear_layer1.weight.grad, mlp.linear_layer1.bias.grad, mlp.linear_layer2.weight.grad,
+           mlp.linear_layer2.bias.grad]
+    for name, a, b, c in zip(("dx", "dW1", "db1", "dW2", "db2"), got, r32, r64):
+        assert a is not None and tuple(a.shape) == tuple(c.shape), name
+        _judge(a.cpu(), b, c, name)
+    # parameters only (frozen input) and input only (frozen head): the unneeded GEMMs are skipped, results unchanged
+    for p in mlp.parameters():
+        p.grad = None
+    head._head(mlp, x.to(DEV), normalize=normalize)[0].backward(gout.to(DEV))
+    assert torch.equal(mlp.linear_layer2.weight.grad, got[3]) and torch.equal(mlp.linear_layer1.weight.grad, got[1])
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    xd2 = x.detach().clone().to(DEV).requires_grad_(True)
+    head._head(mlp, xd2, normalize=normalize)[0].backward(gout.to(DEV))
+    assert torch.equal(xd2.grad, got[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mean_pool_backward_vs_autograd(dtype):
+    """d hidden of get_mean_token_embed against autograd through the oracle's restatement of model/abc_util.py:33-41 (whose
+    forward is pinned by the reference's own fixture): pads get exact zeros, the instruction mask scales, division by S."""
+    B, S, H = 6, 19, 64
+    g = torch.Generator().manual_seed(3)
+    hidden = torch.randn(B, S, H, generator=g).to(dtype)
+    ids = torch.randint(1, 50, (B, S), generator=g)
+    for b, n in enumerate([19, 12, 1, 7, 0, 15]):
+        ids[b, n:] = 0
+    instr = (torch.rand(B, S, generator=g) > 0.3).float()
+    gout = torch.randn(B, H, generator=g).to(dtype)
+    for im in (None, instr):
+        hr = hidden.clone().requires_grad_(True)
+        oracle.get_mean_token_embed(ids, hr, 0, None if im is None else im.to(dtype)).backward(gout)
+        hd = hidden.to(DEV).requires_grad_(True)
+        out = head.get_mean_token_embed(ids.to(DEV), hd, 0, None if im is None else im.to(DEV))
+        assert out.dtype == dtype
+        out.backward(gout.to(DEV))
+        got, ref = hd.grad.cpu(), hr.grad
+        assert got.dtype == dtype and tuple(got.shape) == (B, S, H)
+        if dtype == torch.float32:
+            assert torch.equal(got, ref)
+        else:
+            assert float((got.float() - ref.float()).abs().max()) <= 2 ** -7 * float(ref.float().abs().max())
+        assert float(got[4].float().abs().max()) == 0.0 and float(got[1, 12:].float().abs().max()) == 0.0
+
+
+def test_training_forward_chain_end_to_end():
+    """modeling_abc.py:148-157 as one graph on the GPU: hidden states -> mean pool -> head -> normalise ->
+    compute_contrastive_loss, gradients back to the hidden states, the head and the temperature, against torch-CPU
+    autograd over the oracle's restatements of the same chain."""
+    from vllm_amd import loss as L
+    B, S, H = 24, 11, 128
+    g = torch.Generator().manual_seed(11)
+    ref_mlp, mlp = _trained_pair(H, H, g)
+    hq, hc = torch.randn(B, S, H, generator=g), torch.randn(B, S, H, generator=g)
+    hc = hc + 0.7 * hq
+    ids = torch.randint(1, 9, (B, S), generator=g)
+    ids[:, 8:] = 0
+
+    def chain(pool, mlp_, loss_fn, temp, hq_, hc_, dev):
+        q = torch.nn.functional.normalize(mlp_(pool(ids.to(dev), hq_, 0)).float(), dim=-1) if mlp_ is ref_mlp else \
+            head.embed_head(ids.to(dev), hq_, 0, mlp_)
+        c = torch.nn.functional.normalize(mlp_(pool(ids.to(dev), hc_, 0)).float(), dim=-1) if mlp_ is ref_mlp else \
+            head.embed_head(ids.to(dev), hc_, 0, mlp_)
+        return loss_fn(q, c, temp, 0.1)
+
+    t_ref = oracle.OracleTemperature(0.07)
+    a, b = hq.clone().requires_grad_(True), hc.clone().requires_grad_(True)
+    l_ref, acc_ref = chain(oracle.get_mean_token_embed, ref_mlp, oracle.compute_contrastive_loss, t_ref, a, b, "cpu")
+    l_ref.backward()
+    t_got = L.Temperature(0.07).to(DEV)
+    ad, bd = hq.to(DEV).requires_grad_(True), hc.to(DEV).requires_grad_(True)
+    l_got, acc_got = chain(None, mlp, L.compute_contrastive_loss, t_got, ad, bd, DEV)
+    l_got.backward()
+    assert abs(float(l_got) - float(l_ref)) <= 1e-5 * abs(float(l_ref)) and float(acc_got) == float(acc_ref)
+    for name, x, y in (("d hidden_q", ad.grad.cpu(), a.grad), ("d hidden_c", bd.grad.cpu(), b.grad),
+                       ("dW1", mlp.linear_layer1.weight.grad.cpu(), ref_mlp.linear_layer1.weight.grad),
+                       ("dW2", mlp.linear_layer2.weight.grad.cpu(), ref_mlp.linear_layer2.weight.grad),
+                       ("db2", mlp.linear_layer2.bias.grad.cpu(), ref_mlp.linear_layer2.bias.grad),
+                       ("dtemp", t_got.temp.grad.cpu(), t_ref.temp.grad)):
+        assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-9, name

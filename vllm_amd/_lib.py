@@ -42,7 +42,11 @@ SIGNATURES = {
     "abc_mean_pool_bf16": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _int, _vp, _vp]),
     "abc_mean_pool_f32": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp]),
     "abc_embed_head_workspace_bytes": (_sz, [_int, _int, _int]),
-    "abc_embed_head_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_embed_head_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_embed_head_bwd_workspace_bytes": (_sz, [_int, _int, _int]),
+    "abc_embed_head_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "abc_mean_pool_bwd_bf16": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp]),
+    "abc_mean_pool_bwd_f32": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp]),
     "abc_infonce_bwd": (_int, [_vp, _vp, _vp, _vp, _f32, _vp, _int, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restric
                                                          const float* __restrict__ bias, const float* __restrict__ x,
                                                          int normalize, float* __restrict__ out_f32,
                                                          uint16_t* __restrict__ out_bf16, int8_t* __restrict__ out_i8,
-                                                         float* __restrict__ out_scale) {
+                                                         float* __restrict__ out_scale, float* __restrict__ out_norm) {
     __shared__ float sh[8];
     const int i = blockIdx.x, tid = threadIdx.x;
     const size_t bh = (size_t)B * H;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void head_finish_kernel(const float* __restric
     if ((tid & 63) == 0) sh[tid >> 6] = ss;
     __syncthreads();
     const float nrm = sqrtf((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (out_norm && tid == 0) out_norm[i] = nrm;                   // ||y||: what the backward of the normalise needs
     const float den = normalize ? fmaxf(nrm, 1e-12f) : 1.0f;
     float amax = 0.f;
     for (int j = tid; j < H; j += 256) {
@@ -195,7 +196,7 @@ extern "C" size_t abc_embed_head_workspace_bytes(int B, int H, int Hd) {
 
 extern "C" int abc_embed_head_f32(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
                                   int B, int H, int Hd, int normalize, float* out_f32, void* out_bf16, int8_t* out_i8,
-                                  float* out_scale, void* ws, size_t ws_bytes, void* stream) {
+                                  float* out_scale, float* out_h1, float* out_norm, void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || H <= 0 || Hd <= 0 || (H % 8) || (Hd % 8)) return abc_fail_invalid("embed_head: H and Hd must be positive multiples of 8");
     if (!x || !w1 || !w2 || !out_f32) return abc_fail_invalid("embed_head: null pointer");
     if ((out_i8 == nullptr) != (out_scale == nullptr)) return abc_fail_invalid("embed_head: out_i8 and out_scale go together");
@@ -205,7 +206,7 @@ extern "C" int abc_embed_head_f32(const float* x, const float* w1, const float* 
     if (!ws || ws_bytes < L.total) return abc_fail_ws(L.total, ws_bytes);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)((char*)ws + L.off_part);
-    float* h1 = (float*)((char*)ws + L.off_h1);
+    float* h1 = out_h1 ? out_h1 : (float*)((char*)ws + L.off_h1);      // training keeps selu(x W1^T + b1) for the backward
     auto gemm = nt_gemm_partials_kernel<1>;
     hipError_t e = hipFuncSetAttribute((const void*)gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e != hipSuccess) return abc_fail_hip(e, "embed_head attr");
@@ -215,7 +216,7 @@ extern "C" int abc_embed_head_f32(const float* x, const float* w1, const float* 
     // y = x + h1 W2^T + b2 ; normalise  h1 [B,Hd], W2 [H,Hd]
     hipLaunchKernelGGL(gemm, dim3(((B + 63) / 64) * ((H + 63) / 64), L.sk2), dim3(512), 65536, st, h1, w2, B, H, Hd, L.sk2, part);
     hipLaunchKernelGGL(head_finish_kernel, dim3(B), dim3(256), 0, st, part, L.sk2, B, H, b2, x, normalize, out_f32,
-                       (uint16_t*)out_bf16, out_i8, out_scale);
+                       (uint16_t*)out_bf16, out_i8, out_scale, out_norm);
     e = hipGetLastError();
     return e == hipSuccess ? ABC_OK : abc_fail_hip(e, "embed_head launch");
 }
