@@ -23,6 +23,10 @@ if [ "$part" = 1 ]; then
   done
   timeout -k 10 200 python3 bench.py --nc 412500 --steps 20 --warmup 2 --no-cpu-baseline > $out/shard412k_line.json 2> $out/shard.err
   echo "shard done"; cat $out/shard412k_line.json
+  # the vendor GEMM yardstick on this very box (score GEMM alone, bf16 out, no top-k)
+  timeout -k 10 200 python3 scripts/gemm_yardstick.py > $out/gemm_yardstick.jsonl 2> $out/yardstick.err
+  echo "yardstick done"; cat $out/gemm_yardstick.jsonl
+  python3 scripts/pmc_summary.py $out/pmc_1 $out/pmc_2 $out/pmc_3 $out/pmc_4 > $out/pmc_summary.txt 2>/dev/null || true
 else
   timeout -k 10 500 python3 scripts/bench_configs.py > $out/configs.jsonl 2> $out/configs.err
   echo "configs done"; cat $out/configs.jsonl

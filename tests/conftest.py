@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def free_port() -> int:
+    """A TCP port free right now on 127.0.0.1 (bound to port 0 and released): the rendezvous port of a spawned process
+    group, so that a port left in TIME_WAIT by an earlier run, or a second job on the box, cannot stall the test."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

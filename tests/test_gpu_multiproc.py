@@ -17,6 +17,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
+from conftest import free_port
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gathered_gloo.npz")
@@ -55,7 +56,7 @@ def _run(world, differentiable, port):
 @pytest.mark.parametrize("world", [2, 4])
 def test_compute_gathered_loss_under_process_group(world):
     z = np.load(GOLDEN)
-    got = _run(world, False, 29900 + world)
+    got = _run(world, False, free_port())
     for r in range(world):
         g = lambda k: torch.from_numpy(np.asarray(z[f"w{world}_r{r}_{k}"]))  # noqa: E731
         o = got[r]
@@ -82,7 +83,7 @@ def test_differentiable_gather_under_process_group(world):
         l, _ = oracle.compute_contrastive_loss(qs[r], torch.cat([cs[o] for o in order], 0), temps[r], eps)
         losses.append(l)
     torch.stack(losses).sum().backward()
-    got = _run(world, True, 29950 + world)
+    got = _run(world, True, free_port())
     for r in range(world):
         o = got[r]
         assert abs(float(o["loss"]) - float(losses[r])) <= 1e-5 * abs(float(losses[r]))
@@ -125,7 +126,7 @@ def test_sharded_mining_under_process_group(world):
     want = [t.cpu() for t in search.mine_negatives(qe, ce, 48)]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_mine_rank, args=(world, 29970 + world, ret), nprocs=world, join=True)
+    mp.spawn(_mine_rank, args=(world, free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         idx, vals, s_pos = ret[r]
         assert torch.equal(idx, want[0]), r
