@@ -8,11 +8,13 @@ It restates, on the CPU with torch/numpy, the reference functions listed in
 SURVEY.md section 8(a).  Every function cites the reference file:line it
 follows.  Parity pinning: the reference has no tests or golden vectors of its
 own, so the oracle is pinned against outputs of the reference itself run in the
-build container (``oracle/gen_golden.py`` imports ``model/abc_util.py`` and
-``visualization/neg_mine.py`` from /root/reference and writes small fixtures to
-``tests/golden/``); functions that cannot be imported there (eval_*.py,
-create_negative_index.py: ordinary ImportError/SyntaxError) are
-line-by-line restatements only.
+build container: ``oracle/gen_golden.py`` imports ``model/abc_util.py`` and
+``visualization/neg_mine.py`` from /root/reference, compiles the hot-path function
+definitions of ``evaluate/eval_mscoco.py``, ``evaluate/eval_flickr30k.py`` and
+``pretrain/create_negative_index.py`` out of those files (their modules cannot be
+imported there: ordinary ImportError/SyntaxError), runs
+them on CPU and writes small fixtures to ``tests/golden/``.  Only the MLP head
+(``model/modeling_abc.py`` needs ``timm``) is a restatement without a fixture.
 """
 from .search_oracle import *  # noqa: F401,F403
 from .loss_oracle import *  # noqa: F401,F403
