@@ -13,8 +13,9 @@ build container: ``oracle/gen_golden.py`` imports ``model/abc_util.py`` and
 definitions of ``evaluate/eval_mscoco.py``, ``evaluate/eval_flickr30k.py`` and
 ``pretrain/create_negative_index.py`` out of those files (their modules cannot be
 imported there: ordinary ImportError/SyntaxError), runs
-them on CPU and writes small fixtures to ``tests/golden/``.  Only the MLP head
-(``model/modeling_abc.py`` needs ``timm``) is a restatement without a fixture.
+them on CPU and writes small fixtures to ``tests/golden/``; the ``Linear`` / ``MLP`` /
+``Temperature`` classes of ``model/modeling_abc.py`` (which needs ``timm``) are pinned the
+same way (``head.npz``).
 """
 from .search_oracle import *  # noqa: F401,F403
 from .loss_oracle import *  # noqa: F401,F403

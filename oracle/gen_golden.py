@@ -349,6 +349,60 @@ def gen_glue():
     np.savez_compressed(os.path.join(OUT, "glue.npz"), **fix)
 
 
+def _ref_classes(relpath, names, env):
+    """The named top-level class definitions of a reference file that cannot be imported (see _ref_functions)."""
+    import ast
+    path = os.path.join(REF, relpath)
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), (relpath, [n.name for n in body])
+    ns = dict(env)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def gen_head():
+    """model/modeling_abc.py:9-43 -- Linear, MLP, Temperature -- compiled out of the file (the module needs timm /
+    flash_attn) and run on CPU: a fresh MLP (identity / zero initialisation), a trained-looking one through the training
+    forward's chain F.normalize(mlp_head(x).float(), dim=-1) (:151-154) with autograd gradients of x and of the four
+    parameters, and Temperature.forward."""
+    from torch import nn
+    from torch.nn import init
+    ns = _ref_classes("model/modeling_abc.py", ["Linear", "MLP", "Temperature"], {"torch": torch, "nn": nn, "init": init})
+    MLP, Temperature = ns["MLP"], ns["Temperature"]
+    out = {}
+    g = torch.Generator().manual_seed(2025)
+    H, Hd, B = 64, 72, 9
+    fresh = MLP(H, Hd)
+    out["fresh_w1"], out["fresh_b1"] = fresh.linear_layer1.weight.detach().numpy(), fresh.linear_layer1.bias.detach().numpy()
+    out["fresh_w2"], out["fresh_b2"] = fresh.linear_layer2.weight.detach().numpy(), fresh.linear_layer2.bias.detach().numpy()
+    assert sorted(fresh.state_dict()) == ["linear_layer1.bias", "linear_layer1.weight", "linear_layer2.bias", "linear_layer2.weight"]
+    x = 0.5 * torch.randn(B, H, generator=g)
+    with torch.no_grad():
+        out["x"], out["fresh_y"] = x.numpy(), fresh(x).numpy()
+    mlp = MLP(H, Hd)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=g))
+    for k, v in mlp.state_dict().items():
+        out["p_" + k] = v.detach().numpy().copy()
+    xg = x.clone().requires_grad_(True)
+    emb = torch.nn.functional.normalize(mlp(xg).float(), dim=-1)
+    gout = torch.randn(B, H, generator=g) / H ** 0.5
+    emb.backward(gout)
+    out["emb"], out["gout"], out["dx"] = emb.detach().numpy(), gout.numpy(), xg.grad.numpy()
+    out["dw1"], out["db1"] = mlp.linear_layer1.weight.grad.numpy(), mlp.linear_layer1.bias.grad.numpy()
+    out["dw2"], out["db2"] = mlp.linear_layer2.weight.grad.numpy(), mlp.linear_layer2.bias.grad.numpy()
+    with torch.no_grad():
+        out["y"] = mlp(x).numpy()
+    t = Temperature()
+    out["temp_init"] = t.temp.detach().numpy()
+    s = torch.randn(5, 7, generator=g)
+    out["temp_in"], out["temp_out"] = s.numpy(), t(s).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "head.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     sys.path.insert(0, os.path.dirname(OUT.rstrip("/")).rsplit("/tests", 1)[0])
@@ -359,6 +413,7 @@ def main():
     gen_gathered()
     gen_mean_pool(abc_util)
     gen_glue()
+    gen_head()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -103,7 +103,8 @@ def get_mean_token_embed(input_ids, hidden_state, padding_token_id, instruction_
 
 class OracleMLP(torch.nn.Module):
     """Restates model/modeling_abc.py:9-34 (Linear with identity/zero init, SELU, residual).  The module
-    cannot be imported here (timm / flash_attn missing): parity unpinned beyond torch.nn itself."""
+    cannot be imported here (timm / flash_attn missing); pinned by tests/golden/head.npz, which the reference's own
+    Linear / MLP classes (compiled out of the file by oracle/gen_golden.py::gen_head) produced."""
 
     def __init__(self, embed_size, hidden_size=None):
         super().__init__()

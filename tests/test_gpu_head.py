@@ -246,3 +246,36 @@ def test_training_forward_chain_end_to_end():
                        ("db2", mlp.linear_layer2.bias.grad.cpu(), ref_mlp.linear_layer2.bias.grad),
                        ("dtemp", t_got.temp.grad.cpu(), t_ref.temp.grad)):
         assert float((x - y).abs().max()) <= 2e-4 * float(y.abs().max()) + 1e-9, name
+
+
+def test_head_vs_reference_classes_fixture(golden_dir):
+    """The HIP head (forward, normalise, backward) and loss.Temperature against what model/modeling_abc.py:9-43's own MLP and
+    Temperature returned on CPU (tests/golden/head.npz, oracle/gen_golden.py::gen_head): state-dict names load unchanged,
+    fresh initialisation equal, forward within 1e-6 of the row scale, gradients within 2e-6 of their scale."""
+    from vllm_amd import loss as L
+    z = np.load(os.path.join(golden_dir, "head.npz"))
+    t = lambda k: torch.from_numpy(np.asarray(z[k]))  # noqa: E731
+    H, Hd = 64, 72
+    fresh = head.MLP(H, Hd)
+    assert torch.equal(fresh.linear_layer1.weight.detach(), t("fresh_w1")) and torch.equal(fresh.linear_layer2.weight.detach(), t("fresh_w2"))
+    assert float(fresh.linear_layer1.bias.abs().max()) == 0.0 and float(fresh.linear_layer2.bias.abs().max()) == 0.0
+    x = t("x")
+    with torch.no_grad():
+        y = fresh.to(DEV)(x.to(DEV)).cpu()
+    assert float((y - t("fresh_y")).abs().max()) <= 1e-6 * float(t("fresh_y").abs().max())
+    mlp = head.MLP(H, Hd)
+    mlp.load_state_dict({k[2:]: t(k) for k in z.files if k.startswith("p_")})
+    mlp = mlp.to(DEV)
+    xd = x.clone().to(DEV).requires_grad_(True)
+    emb = head._head(mlp, xd, normalize=True)[0]
+    emb.backward(t("gout").to(DEV))
+    close = lambda a, b, tol: float((a.cpu() - b).abs().max()) <= tol * float(b.abs().max())  # noqa: E731
+    assert close(emb.detach(), t("emb"), 1e-6)
+    for name, got in (("dx", xd.grad), ("dw1", mlp.linear_layer1.weight.grad), ("db1", mlp.linear_layer1.bias.grad),
+                      ("dw2", mlp.linear_layer2.weight.grad), ("db2", mlp.linear_layer2.bias.grad)):
+        assert close(got, t(name), 2e-6), name
+    with torch.no_grad():
+        assert close(mlp(x.to(DEV)), t("y"), 1e-6)
+    temp = L.Temperature().to(DEV)
+    assert torch.equal(temp.temp.detach().cpu(), t("temp_init"))
+    assert torch.equal(temp(t("temp_in").to(DEV)).detach().cpu(), t("temp_out"))          # x / temp: one IEEE division
