@@ -132,3 +132,38 @@ def test_sharded_mining_under_process_group(world):
         assert torch.equal(idx, want[0]), r
         assert torch.equal(vals, want[1]), r
         assert torch.equal(s_pos, want[2]), r
+
+
+def _driver_rank(rank, world, port, path):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vllm_amd import mining
+    mining.create_negative_index(path, top=100, compute="f32", block=96, resume=False)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mining_driver_under_process_group(world, tmp_path, golden_dir):
+    """mining.create_negative_index (the pipelined driver) with the corpus row-sharded over 2 / 3 ranks: same negatives.json,
+    byte for byte, as the one-process run -- on the reference-run fixture inputs, whose short rows make every rank take the
+    tail-fill path (a second, collective search) inside the write-out of a block -- and the reference's own lists."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from glue_util import Glue
+    from vllm_amd import mining
+    g = Glue(golden_dir)
+    q, c = g.mining_inputs()
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    mining.save_embeddings(one, q, c)
+    mining.save_embeddings(many, q, c)
+    want = open(mining.create_negative_index(one, top=100, compute="f32", block=96)).read()
+    mp.spawn(_driver_rank, args=(world, free_port(), many), nprocs=world, join=True)
+    got = open(os.path.join(many, "negatives.json")).read()
+    assert got == want
+    assert not os.path.exists(os.path.join(many, mining.PARTS_DIR))
+    g.check_negatives({int(k): v for k, v in json.loads(got).items()})
