@@ -54,12 +54,10 @@ def test_phase_loop_is_clean(isa, dt, mfma, per_phase):
     assert "scratch_" not in body, "the accumulators (or spills) went to scratch: is the unroll threshold flag set?"
     blocks = re.split(r"^\.LBB\d+_\d+:", body, flags=re.M)
     loop = [b for b in blocks if b.count(mfma) >= 32]
-    if dt == 1:
-        # int8 peels the first phase of a tile (its products start from C = 0 instead of zeroed accumulators): that copy
-        # comes first in the code, the loop proper is the last two blocks
-        assert len(loop) == 4, [b.count(mfma) for b in blocks if mfma in b]
-        loop = loop[2:]
-    assert len(loop) == 2, [b.count(mfma) for b in blocks if mfma in b]
+    # the first phase of a tile is peeled (its products start from C = 0 instead of zeroed accumulators): that copy comes
+    # first in the code, the loop proper is the last two blocks
+    assert len(loop) == 4, [b.count(mfma) for b in blocks if mfma in b]
+    loop = loop[2:]
     text = "".join(loop)
     assert text.count(mfma) == per_phase
     assert text.count("ds_read_b128") == 40
