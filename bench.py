@@ -19,10 +19,14 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# multi-process GPU work on this image needs dmabuf IPC (the host driver has no legacy IPC: RCCL fails with
+# "hipIpcGetMemHandle: invalid argument" without it); already exported on the boxes, kept here for any other launcher
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+import torch                                                              # noqa: E402
+import torch.distributed as dist                                          # noqa: E402
+
+ROOT =os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NC_FULL = 3_300_000
