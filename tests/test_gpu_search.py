@@ -167,3 +167,35 @@ def test_empty_and_error_paths():
         kernels.topk(q, q, 129)
     with pytest.raises(_lib.AbcError):
         kernels.topk(q.cpu(), q.cpu(), 2)
+
+
+@pytest.mark.parametrize("compute,d", [("f32", 100), ("f32", 7), ("bf16", 100), ("bf16", 200), ("i8", 100)])
+def test_any_embedding_width(compute, d):
+    """The reference's get_topk_candidates / negatives_for_sample take any D (torch.matmul); the kernels take rows of whole
+    128-byte pieces: Embeddings pads other widths with zero columns, which changes no score.  Exact-grid data (integers / 16):
+    every score is exact in any summation order, so values AND indices equal the oracle's (ties: lower index first)."""
+    from vllm_amd import search
+    g = torch.Generator().manual_seed(d)
+    q = torch.randint(-8, 9, (300, d), generator=g).float() / 16
+    c = torch.randint(-8, 9, (1500, d), generator=g).float() / 16
+    if compute == "i8":
+        q[:, 0], c[:, 0] = 127 / 16, 127 / 16                      # per-row scale 1/16 exactly: quantised values = 16 x
+        qa, sa = oracle.quantize_i8(q)
+        cb, sb = oracle.quantize_i8(c)
+        rv, ri = oracle.topk_ref_i8(qa, sa, cb, sb, 10)
+    else:
+        rv, ri = oracle.topk_ref(q, c, 10)
+    qe = search.Embeddings(q, compute)
+    ce = search.Embeddings(c, compute, qe.data.device)
+    assert ce.shape[1] % (128 // ce.data.element_size()) == 0 and ce.shape[1] - d < 128
+    v, i, _ = search.topk(qe, ce, 10)
+    assert torch.equal(v.cpu(), rv) and torch.equal(i.cpu(), ri)
+    if compute != "i8":
+        idx, vals, s_pos = search.mine_negatives(qe.rows(0, 200), ce, 10)
+        mv, mi, mp = oracle.mine_negatives_ref(q[:200], c, 10)
+        assert torch.equal(s_pos.cpu(), mp)
+        keep = mi >= 0
+        assert torch.equal(idx.cpu()[keep], mi[keep]) and torch.equal(vals.cpu()[keep], mv[keep])
+        images = [(f"q{j}", q[j:j + 1]) for j in range(40)]
+        cands = [(f"c{j}", c[j:j + 1]) for j in range(500)]
+        assert search.get_topk_candidates(images, cands, 5, compute=compute) == oracle.get_topk_candidates(images, cands, 5)

@@ -182,7 +182,7 @@ def upload(x: torch.Tensor, compute: str, device=None, rows: Optional[Tuple[int,
             if pos + n < hi:
                 st.prefetch(pos + n, min(pos + n + block, hi))
             if out.data is None:
-                out.data = torch.empty((hi - lo, x.shape[1]), dtype=part.data.dtype, device=dev)
+                out.data = torch.empty((hi - lo, part.data.shape[1]), dtype=part.data.dtype, device=dev)
                 out.scale = None if part.scale is None else torch.empty((hi - lo,), dtype=torch.float32, device=dev)
             out.data[pos - lo:pos - lo + n] = part.data
             if out.scale is not None:

@@ -47,9 +47,16 @@ class Embeddings:
             self.data = x if x.dtype == torch.bfloat16 else kernels.cast_bf16(x.float())
         else:
             self.data = x.float().contiguous()
+        # the kernels take rows of whole 128-byte pieces (64 bf16 / 32 fp32 / 128 int8 elements): any other width (the
+        # reference's get_topk_candidates takes any D) is padded with zero columns once, here, which changes no score
+        per = 128 // self.data.element_size()
+        extra = (-self.data.shape[1]) % per if self.data.dim() == 2 else 0
+        if extra:
+            self.data = torch.nn.functional.pad(self.data, (0, extra))
 
     @property
     def shape(self):
+        """[rows, columns as resident: D rounded up to whole 128-byte pieces]"""
         return self.data.shape
 
     def rows(self, lo: int, hi: int) -> "Embeddings":
