@@ -1,0 +1,71 @@
+"""Soak run of the search kernels against the oracle: seeded random problems for a time budget (default 240 s).
+
+    python scripts/soak_random.py [seconds] [seed]
+
+Exact-grid data (integers / 16, d <= 256: every score is exact in fp32 in any summation order, ties are everywhere), so
+values AND indices must EQUAL the oracle's (ties: lower index first) for all three compute types, with and without the
+0.95-positive bound: ragged query blocks and tiles, k from 1 to 128, corpora from one row to several hundred tiles per
+split (bounds, refreshes, compactions, both descents).  Test infrastructure: uses oracle/ as the checker."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import oracle  # noqa: E402
+from vllm_amd import search  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+rng = torch.Generator().manual_seed(seed)
+ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))  # noqa: E731
+dev = torch.device("cuda:0")
+t0 = time.time()
+case = 0
+while time.time() - t0 < budget:
+    compute = ("bf16", "f32", "i8")[case % 3]
+    d = (64, 128, 256)[ri(0, 2)]
+    nq = (ri(1, 300), ri(300, 2000), ri(7000, 9000))[ri(0, 2)]
+    nc = (ri(1, 200), ri(200, 5000), ri(5000, 40000), ri(40000, 300000))[ri(0, 3)]
+    k = (ri(1, 16), ri(16, 64), ri(65, 128))[ri(0, 2)]
+    spread = (1, 2, 8)[ri(0, 2)]                                   # few distinct values -> many ties
+    g = torch.Generator().manual_seed(seed * 100003 + case)
+    q = torch.randint(-spread, spread + 1, (nq, d), generator=g).float() / 16
+    c = torch.randint(-spread, spread + 1, (nc, d), generator=g).float() / 16
+    bound = case % 2 == 1 and nc >= nq
+    if bound:                                                      # positives that ARE similar: q_i = c_i with a few flips
+        q = c[:nq].clone()
+        flip = torch.rand((nq, d), generator=g) < 0.1
+        q[flip] = -q[flip]
+    if compute == "i8":
+        q[:, 0], c[:, 0] = 127 / 16, 127 / 16                      # per-row scale 1/16 exactly
+    qe = search.Embeddings(q, compute, dev)
+    ce = search.Embeddings(c, compute, dev)
+    tag = (case, compute, nq, nc, d, k, spread, bound)
+    if bound:
+        idx, vals, s_pos = search.mine_negatives(qe, ce, k, fill_masked_tail=False)
+        ub = (s_pos * 0.95).cpu()
+    else:
+        vals, idx, _ = search.topk(qe, ce, k)
+        ub = None
+    torch.cuda.synchronize()
+    vals, idx = vals.cpu(), idx.cpu()
+    if compute == "i8":
+        rv, rix = oracle.topk_ref_i8(qe.data.cpu()[:, :d], qe.scale.cpu(), ce.data.cpu()[:, :d], ce.scale.cpu(), k, upper_bound=ub)
+    else:
+        rv, rix = oracle.topk_ref(q, c, k, upper_bound=ub)
+    if rv.shape[1] < k:                                            # corpus shorter than k: the oracle returns nc columns
+        pad = k - rv.shape[1]
+        rv = torch.cat([rv, torch.full((nq, pad), float("-inf"))], dim=1)
+        rix = torch.cat([rix, torch.full((nq, pad), -1, dtype=torch.int64)], dim=1)
+    ok = torch.equal(idx, rix) and torch.equal(vals, rv)
+    print(("ok  " if ok else "FAIL"), tag, f"{time.time() - t0:.0f}s", flush=True)
+    if not ok:
+        bad = (idx != rix).any(dim=1).nonzero().flatten()
+        print("rows differing:", bad[:10].tolist(), "of", nq)
+        r = int(bad[0]) if len(bad) else 0
+        print("got", idx[r].tolist()[:16], vals[r].tolist()[:8])
+        print("ref", rix[r].tolist()[:16], rv[r].tolist()[:8])
+        sys.exit(1)
+    case += 1
+print(f"{case} cases, all equal to the oracle")
