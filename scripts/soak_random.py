@@ -4,7 +4,7 @@
 
 Exact-grid data (integers / 16, d <= 256: every score is exact in fp32 in any summation order, ties are everywhere), so
 values AND indices must EQUAL the oracle's (ties: lower index first) for all three compute types, with and without the
-0.95-positive bound: ragged query blocks and tiles, k from 1 to 128, corpora from one row to several hundred tiles per
+0.95-positive bound, and for neg_mine.batch (top-k + compare-count): ragged query blocks and tiles, k from 1 to 128, corpora from one row to several hundred tiles per
 split (bounds, refreshes, compactions, both descents).  Test infrastructure: uses oracle/ as the checker."""
 import sys
 import time
@@ -42,6 +42,20 @@ while time.time() - t0 < budget:
     qe = search.Embeddings(q, compute, dev)
     ce = search.Embeddings(c, compute, dev)
     tag = (case, compute, nq, nc, d, k, spread, bound)
+    if case % 4 == 3 and compute != "i8" and nc >= nq and k <= nc:
+        # neg_mine.batch (visualization/neg_mine.py:21-42): top-k, the fraction of candidates above the positive, the positive
+        i0 = ri(0, nq - 1)
+        bs = ri(1, nq)
+        got = search.batch(qe, ce, i0, bs, k)
+        ref = oracle.neg_mine_batch(q, c, i0, bs, k)
+        ok = all(torch.equal(a, b) for a, b in zip(got, ref))
+        print(("ok  " if ok else "FAIL"), "batch", tag, i0, bs, f"{time.time() - t0:.0f}s", flush=True)
+        if not ok:
+            for name, a, b in zip(("score", "idx", "frac", "pos"), got, ref):
+                print(name, "equal" if torch.equal(a, b) else "DIFFERS")
+            sys.exit(1)
+        case += 1
+        continue
     if bound:
         idx, vals, s_pos = search.mine_negatives(qe, ce, k, fill_masked_tail=False)
         ub = (s_pos * 0.95).cpu()
