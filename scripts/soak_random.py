@@ -1,6 +1,6 @@
 """Soak run of the search kernels against the oracle: seeded random problems for a time budget (default 240 s).
 
-    python scripts/soak_random.py [seconds] [seed]
+    python scripts/soak_random.py [seconds] [seed] [first case]
 
 Exact-grid data (integers / 16, d <= 256: every score is exact in fp32 in any summation order, ties are everywhere), so
 values AND indices must EQUAL the oracle's (ties: lower index first) for all three compute types, with and without the
@@ -17,6 +17,7 @@ from vllm_amd import search  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0             # skip the cases before this one (same random sequence)
 rng = torch.Generator().manual_seed(seed)
 ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))  # noqa: E731
 dev = torch.device("cuda:0")
@@ -29,10 +30,15 @@ while time.time() - t0 < budget:
     nc = (ri(1, 200), ri(200, 5000), ri(5000, 40000), ri(40000, 300000))[ri(0, 3)]
     k = (ri(1, 16), ri(16, 64), ri(65, 128))[ri(0, 2)]
     spread = (1, 2, 8)[ri(0, 2)]                                   # few distinct values -> many ties
+    bound = case % 2 == 1 and nc >= nq
+    batch_mode = case % 4 == 3 and compute != "i8" and nc >= nq and k <= nc
+    i0, bs = (ri(0, nq - 1), ri(1, nq)) if batch_mode else (0, 0)
+    if case < first:
+        case += 1
+        continue
     g = torch.Generator().manual_seed(seed * 100003 + case)
     q = torch.randint(-spread, spread + 1, (nq, d), generator=g).float() / 16
     c = torch.randint(-spread, spread + 1, (nc, d), generator=g).float() / 16
-    bound = case % 2 == 1 and nc >= nq
     if bound:                                                      # positives that ARE similar: q_i = c_i with a few flips
         q = c[:nq].clone()
         flip = torch.rand((nq, d), generator=g) < 0.1
@@ -42,10 +48,8 @@ while time.time() - t0 < budget:
     qe = search.Embeddings(q, compute, dev)
     ce = search.Embeddings(c, compute, dev)
     tag = (case, compute, nq, nc, d, k, spread, bound)
-    if case % 4 == 3 and compute != "i8" and nc >= nq and k <= nc:
+    if batch_mode:
         # neg_mine.batch (visualization/neg_mine.py:21-42): top-k, the fraction of candidates above the positive, the positive
-        i0 = ri(0, nq - 1)
-        bs = ri(1, nq)
         got = search.batch(qe, ce, i0, bs, k)
         ref = oracle.neg_mine_batch(q, c, i0, bs, k)
         ok = all(torch.equal(a, b) for a, b in zip(got, ref))
@@ -53,6 +57,11 @@ while time.time() - t0 < budget:
         if not ok:
             for name, a, b in zip(("score", "idx", "frac", "pos"), got, ref):
                 print(name, "equal" if torch.equal(a, b) else "DIFFERS")
+                if not torch.equal(a, b):
+                    rows = (a != b).reshape(a.shape[0], -1).any(dim=1).nonzero().flatten()
+                    print(" rows", rows[:20].tolist(), "of", a.shape[0], "n =", len(rows))
+                    r = int(rows[0])
+                    print(" got", a[r].flatten()[:8].tolist(), "ref", b[r].flatten()[:8].tolist(), "x nc:", (a[r] * nc).flatten()[:4].tolist(), (b[r] * nc).flatten()[:4].tolist())
             sys.exit(1)
         case += 1
         continue

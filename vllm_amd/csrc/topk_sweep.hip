@@ -314,7 +314,7 @@ void sweep_plan(int64_t nq, int64_t nc, int k, SweepPlan* pl) {
     }
     int s = 256 / pl->qblocks_per_launch;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;              // one query block (a per-sample call, create_negative_index.py:45-52): every CU takes a split
     if (s > pl->n_tiles) s = pl->n_tiles;
     if (s < 1) s = 1;
     pl->n_splits = s;
