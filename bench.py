@@ -65,6 +65,24 @@ def gen_rows(lo: int, hi: int, mu, seed: int, want_q: bool):
     return out
 
 
+_RESULT_OUT = None
+
+
+def _only_json_on_stdout():
+    """RCCL prints a version banner to STDOUT from C when the first communicator comes up (seen on the box: five lines
+    before the result).  The contract is ONE JSON line on stdout: everything that writes to file descriptor 1 from here on
+    goes to stderr, and the result line alone goes to the real stdout."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(result):
+    print(json.dumps(result), file=_RESULT_OUT, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +98,7 @@ def main():
                          "(fp32, --nc rows, default 412 500) written to local disk -> negatives.json through "
                          "vllm_amd.mining.create_negative_index, beside the rate of the same job with the queries resident in HBM")
     args = ap.parse_args()
+    _only_json_on_stdout()
     if args.from_files:
         return from_files_mode(args)
 
@@ -100,6 +119,19 @@ def main():
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # rank's-eye rehearsal of the N = 8 step on ONE GPU (ABC_BENCH_RANK_OF=8): this process plays one of 8 ranks -- a
+    # 1/8 shard, 8 x 8192 queries per step, the whole exchange (packed sweep, all-gather, merge, all-reduce of s_pos)
+    # through RCCL under a one-rank group -- so everything but the wire time of the collectives is measured
+    rank_of = int(os.environ.get("ABC_BENCH_RANK_OF", "0"))
+    if rank_of > 1 and world != 1:
+        raise SystemExit("ABC_BENCH_RANK_OF is a one-process rehearsal")
+    if rank_of > 1:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(so.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -112,9 +144,9 @@ def main():
     seed = 1234
     nc = args.nc
     mu = centres(dev, seed)
-    lo, hi = parallel.shard_bounds(nc, world, rank)
+    lo, hi = parallel.shard_bounds(nc, max(world, rank_of, 1), rank)
     shard = search.Embeddings(gen_rows(lo, hi, mu, seed, want_q=False), "bf16", dev)
-    corpus = parallel.ShardedCorpus(shard, lo, nc, backend=None)
+    corpus = parallel.ShardedCorpus(shard, lo, hi if rank_of > 1 else nc, backend=None, exchange=True if rank_of > 1 else None)
 
     # time the sweep (the dominant kernel) on its own with events on the launch stream
     sweep_ms = []
@@ -132,7 +164,7 @@ def main():
     if corpus.backend.topk_packed is not None:
         corpus.backend.topk_packed = timed(corpus.backend.topk_packed)  # N > 1: sweep + merge to packed keys
 
-    bq = QUERIES_PER_GPU_STEP * world
+    bq = QUERIES_PER_GPU_STEP * max(world, rank_of, 1)
     batches = []
     if args.full_job:
         # every row of the pair table is a query (create_negative_index.py:37): all of them resident in HBM (27 GB
@@ -145,7 +177,7 @@ def main():
             batches.append((s * bq, all_q.rows(s * bq, min((s + 1) * bq, nc))))
     else:
         for s in range(args.steps + args.warmup):
-            r0 = (s * bq) % max(nc - bq, 1)
+            r0 = (s * bq) % max((hi - lo if rank_of > 1 else nc) - bq, 1)      # (rehearsal: positives inside the one shard)
             batches.append((r0, search.Embeddings(gen_rows(r0, r0 + bq, mu, seed, want_q=True), "bf16", dev)))
     n_batches = len(batches)
     n_queries = sum(b[1].shape[0] for b in batches[args.warmup:])
@@ -229,9 +261,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(batches[-1], shard, nc, out, dev)
 
+    if rank_of > 1:
+        result["rehearsal"] = (f"one process playing rank 0 of {rank_of}: shard of {hi - lo} rows, {bq} queries per step, the exchange "
+                               "through RCCL under a one-rank group (no wire time)")
     if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        _emit(result)
+    if world > 1 or rank_of > 1:
         dist.destroy_process_group()
 
 
@@ -308,7 +343,7 @@ def from_files_mode(args):
                            "files_written_s": t_write, "page_cache": "files written just before the run: reads come from the page cache",
                            "check": f"negatives.json == resident-query lists on {len(rows)} sampled rows, {len(got)} rows in all"},
         }
-        print(json.dumps(result), flush=True)
+        _emit(result)
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

@@ -60,7 +60,8 @@ def hip_backend() -> Backend:
 class ShardedCorpus:
     """This rank's rows [lo, hi) of an n_total-row corpus."""
 
-    def __init__(self, shard, lo: int, n_total: int, group=None, backend: Optional[Backend] = None):
+    def __init__(self, shard, lo: int, n_total: int, group=None, backend: Optional[Backend] = None,
+                 exchange: Optional[bool] = None):
         if n_total >= MAX_ROWS:
             raise ValueError(f"n_total={n_total}: global row indices travel in the 32-bit index field of the packed "
                              f"(score, index) keys; a sharded corpus holds at most {MAX_ROWS - 1} rows")
@@ -70,6 +71,12 @@ class ShardedCorpus:
         self.backend = backend or hip_backend()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # the exchange (packed lists -> all-gather -> merge; all-reduce of s_pos) runs whenever there are several ranks;
+        # exchange=True forces it under a ONE-rank group too: the only way to execute the RCCL calls on a one-GPU box
+        # (tests/test_gpu_multiproc.py::test_rccl_calls_with_one_rank)
+        self.exchange = (self.world > 1) if exchange is None else bool(exchange)
+        if self.exchange and not dist.is_initialized():
+            raise ValueError("exchange=True needs an initialised process group")
 
     # -- exchange steps -------------------------------------------------------------------------
     def _host_staged(self, t: torch.Tensor) -> bool:
@@ -78,10 +85,10 @@ class ShardedCorpus:
         thread keeps enqueueing kernels (gloo stages device tensors on its own worker threads and synchronises streams
         there): scripts/gloo_device_diag.py, DESIGN.md section 5.
         RCCL (backend "nccl", the production path) takes the device tensors as they are."""
-        return t.is_cuda and self.world > 1 and dist.get_backend(self.group) == "gloo"
+        return t.is_cuda and self.exchange and dist.get_backend(self.group) == "gloo"
 
     def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if not self.exchange:
             return t.unsqueeze(0)
         # concatenated along dim 0 (the form both RCCL and gloo accept), viewed as [world, ...]
         dev = t.device
@@ -100,7 +107,7 @@ class ShardedCorpus:
         if a < b:
             s[a - offset:b - offset] = self.backend.rowdot(q.rows(a - offset, b - offset),
                                                            self.shard.rows(a - self.lo, b - self.lo))
-        if self.world > 1:
+        if self.exchange:
             if self._host_staged(s):                        # gloo: through host memory (see _host_staged)
                 h = s.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -117,7 +124,7 @@ class ShardedCorpus:
         and its P-way merge is enqueued, so at most two chunks' buffers are alive.  (A backend without the packed pair --
         CPU-side tests of the exchange logic -- exchanges (value f32, index i64) with two all-gathers.)"""
         n = q.shape[0]
-        if self.world == 1:
+        if not self.exchange:
             return self.backend.topk(q, self.shard, k, upper_bound, self.lo)
         packed = self.backend.topk_packed is not None and self.backend.merge_packed is not None
         outs_v, outs_i = [], []
@@ -169,7 +176,7 @@ class ShardedCorpus:
         s_pos = self.positive_scores(q, offset)
         ub = s_pos * ratio
         v, i = self.topk(q, k, upper_bound=ub, chunk=chunk)
-        if fill_masked_tail and self.world > 1:
+        if fill_masked_tail and self.exchange:
             fill_masked_tail_rows(i, ub, lambda rows: self.topk(q.take(rows), k))
         elif fill_masked_tail:
             fill_masked_tail_rows(i, ub, lambda rows: self.backend.topk(q.take(rows), self.shard, k, None, self.lo))
