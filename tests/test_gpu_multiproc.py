@@ -107,7 +107,7 @@ def _mine_rank(rank, world, port, ret):
     lo, hi = parallel.shard_bounds(c.shape[0], world, rank)
     qe = search.Embeddings(q, "bf16", "cuda:0")
     sc = parallel.ShardedCorpus(search.Embeddings(c[lo:hi], "bf16", "cuda:0"), lo, c.shape[0])
-    idx, vals, s_pos = sc.mine_negatives(qe, 48, chunk=256)    # 3 chunks: the pipelined exchange, ragged last chunk
+    idx, vals, s_pos = sc.mine_negatives(qe, 48, chunk=256)    # 3 chunks through the exchange, ragged last chunk
     torch.cuda.synchronize()
     ret[rank] = (idx.cpu(), vals.cpu(), s_pos.cpu())
     dist.barrier()
@@ -180,7 +180,7 @@ def _rccl_one_rank_main(rank, port, ret):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)           # as bench.py does for N > 1
     from vllm_amd import loss as L, parallel, search
     out = {}
-    # -- the sharded search's exchange: packed sweep -> asynchronous all_gather_into_tensor (int64 keys) -> wait -> merge;
+    # -- the sharded search's exchange: packed sweep -> all_gather_into_tensor (int64 keys) -> device merge;
     # all_reduce(SUM) of the positive scores; three chunks through the pipelined loop
     q, c = oracle.make_clustered(700, 6000, 128, seed=12, n_centres=8)
     q, c = oracle.bf16_round(q), oracle.bf16_round(c)
@@ -214,7 +214,7 @@ def _rccl_one_rank_main(rank, port, ret):
 def test_rccl_calls_with_one_rank():
     """The box has one GPU and RCCL takes one rank per device: a ONE-rank "nccl" group is the only way to execute the
     RCCL calls of the product here (every multi-rank test above runs under gloo with host staging).  ShardedCorpus with
-    exchange=True goes through the full exchange -- packed sweep, asynchronous all_gather_into_tensor, wait, device merge,
+    exchange=True goes through the full exchange -- packed sweep, all_gather_into_tensor, device merge,
     all_reduce of s_pos -- and must reproduce the unsharded search bit for bit; the loss's gather, its reduce-scatter
     backward and the collectives bench.py issues for N > 1 run too.  What one rank cannot show is xGMI traffic and
     cross-rank ordering: the first multi-rank RCCL run is the driver's."""

@@ -119,29 +119,19 @@ class ShardedCorpus:
     def topk(self, q, k: int, upper_bound: Optional[torch.Tensor] = None, chunk: int = 8192
              ) -> Tuple[torch.Tensor, torch.Tensor]:
         """Exact global top-k of every query, replicated on every rank.  Queries go through the local sweep in chunks;
-        a chunk's lists leave the sweep as packed 8-byte keys (score and global index) and cross the GPUs in ONE
-        all-gather of k * 8 bytes per query, enqueued asynchronously; while chunk i+1 sweeps, chunk i's gather completes
-        and its P-way merge is enqueued, so at most two chunks' buffers are alive.  (A backend without the packed pair --
-        CPU-side tests of the exchange logic -- exchanges (value f32, index i64) with two all-gathers.)"""
+        a chunk's lists leave the sweep as packed 8-byte keys (score and global index), cross the GPUs in ONE all-gather of
+        k * 8 bytes per query and are merged on the device before the next chunk's sweep is enqueued.  The order on the
+        stream is sweep, gather, merge, sweep, ...: the sweep owns every CU (one workgroup per CU with all of its registers
+        and LDS), so a collective enqueued beside it does not overlap with it -- it can only race it for CUs at the
+        boundary between two sweeps, and a rank whose collective lost that race would hold its peers' collective kernels
+        spinning for a whole sweep.  In order, the gather has the chip to itself for the ~0.1 ms it takes.
+        (A backend without the packed pair -- CPU-side tests of the exchange logic -- exchanges (value f32, index i64)
+        with two all-gathers.)"""
         n = q.shape[0]
         if not self.exchange:
             return self.backend.topk(q, self.shard, k, upper_bound, self.lo)
         packed = self.backend.topk_packed is not None and self.backend.merge_packed is not None
         outs_v, outs_i = [], []
-        pending = None
-
-        def finish(p):
-            works, bufs, keep, dev, rows = p
-            for w in works:
-                w.wait()
-            bufs = [b.to(dev) for b in bufs]
-            if packed:
-                mv, mi = self.backend.merge_packed(bufs[0].view(self.world, rows, k))
-            else:
-                mv, mi = self.backend.merge(bufs[0].view(self.world, rows, k), bufs[1].view(self.world, rows, k), self.n_total)
-            outs_v.append(mv)
-            outs_i.append(mi)
-
         for a in range(0, max(n, 1), chunk):
             b = min(n, a + chunk)
             qc = q if (a == 0 and b == n) else q.rows(a, b)
@@ -153,14 +143,17 @@ class ShardedCorpus:
             dev = parts[0].device
             if self._host_staged(parts[0]):                 # gloo: the lists cross in host memory
                 parts = [t.cpu() for t in parts]
-            parts = [t.contiguous() for t in parts]
-            bufs = [torch.empty((self.world * t.shape[0], k), dtype=t.dtype, device=t.device) for t in parts]
-            works = [dist.all_gather_into_tensor(g, t, group=self.group, async_op=True) for g, t in zip(bufs, parts)]
-            if pending is not None:                         # chunk i-1: its gather has had this chunk's sweep to complete
-                finish(pending)
-            pending = (works, bufs, parts, dev, b - a)      # parts stay alive until the collective has read them
-        if pending is not None:
-            finish(pending)
+            bufs = []
+            for t in parts:
+                g = torch.empty((self.world * t.shape[0], k), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(g, t.contiguous(), group=self.group)
+                bufs.append(g.to(dev).view(self.world, b - a, k))
+            if packed:
+                mv, mi = self.backend.merge_packed(bufs[0])
+            else:
+                mv, mi = self.backend.merge(bufs[0], bufs[1], self.n_total)
+            outs_v.append(mv)
+            outs_i.append(mi)
         if len(outs_v) == 1:
             return outs_v[0], outs_i[0]
         return torch.cat(outs_v, dim=0), torch.cat(outs_i, dim=0)
