@@ -73,7 +73,7 @@ class ShardedCorpus:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # the exchange (packed lists -> all-gather -> merge; all-reduce of s_pos) runs whenever there are several ranks;
         # exchange=True forces it under a ONE-rank group too: the only way to execute the RCCL calls on a one-GPU box
-        # (tests/test_gpu_multiproc.py::test_rccl_calls_with_one_rank)
+        # (tests/test_gpu_zrccl_one_rank.py)
         self.exchange = (self.world > 1) if exchange is None else bool(exchange)
         if self.exchange and not dist.is_initialized():
             raise ValueError("exchange=True needs an initialised process group")
