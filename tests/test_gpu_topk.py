@@ -154,3 +154,36 @@ def test_several_launches_per_call():
     want_lo = ((s > s_ref[:, None].double()) & gap).sum(1)
     want_hi = ((s > s_ref[:, None].double()) | ~gap).sum(1)
     assert bool(((r.cpu() >= want_lo) & (r.cpu() <= want_hi)).all())
+
+
+@pytest.mark.parametrize("d", [3, 100, 128, 3584, 8192, 8196, 10000])
+def test_quantize_i8_equals_the_oracle_at_any_width(d):
+    """abc_quantize_i8 (rows of up to 8192 floats, a multiple of 4: one 16-byte-load pass held in registers, packed stores;
+    anything else: two scalar passes) against the oracle's rule, values and scales bit for bit -- zero rows, one huge
+    element, halves that round to even."""
+    from vllm_amd import kernels
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn((37, d), generator=g)
+    x[3] = 0.0
+    x[5, d // 2] = 1e4
+    x[7] = torch.arange(d, dtype=torch.float32) % 255 - 127                      # exact grid: scale 1, nothing to round
+    x[8] = (torch.arange(d, dtype=torch.float32) % 255 - 127) / 2                  # halves: rint goes to even
+    q8, s8 = kernels.quantize_i8(x.to(torch.device("cuda:0")))
+    rq, rs = oracle.quantize_i8(x)
+    assert torch.equal(s8.cpu(), rs) and torch.equal(q8.cpu(), rq)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 4099, 1 << 20])
+def test_cast_bf16_equals_torch_rounding(n):
+    """abc_cast_bf16 against torch's round-to-nearest-even, incl. ties, infinities and values that round up into the next
+    exponent; an aligned and a misaligned buffer."""
+    from vllm_amd import kernels
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn((n + 1,), generator=g) * 3
+    x[0] = 1.00390625                                   # exactly halfway between two bf16 values: to even
+    if n > 8:
+        x[1:8] = torch.tensor([float("inf"), -float("inf"), 0.0, -0.0, 3.3895313892515355e38, 1.0039062, 65280.0])
+    xd = x.to(torch.device("cuda:0"))
+    for view in (xd[:n], xd[1:]):                       # the second view starts 4 bytes into the buffer
+        got = kernels.cast_bf16(view.reshape(1, -1))
+        assert torch.equal(got.reshape(-1), view.to(torch.bfloat16))

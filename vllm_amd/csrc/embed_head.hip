@@ -33,32 +33,55 @@ __global__ __launch_bounds__(256) void mean_pool_kernel(const void* __restrict__
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
     const int64_t* idr = ids + (size_t)b * S;
     const float* ir = instr ? instr + (size_t)b * S : nullptr;
-    for (int s = 0; s < S; ++s) {
-        if (idr[s] == pad_id) continue;                          // uniform over the workgroup
-        const float w = ir ? ir[s] : 1.0f;
-        if (w == 0.0f) continue;
-        const size_t row = ((size_t)b * S + s) * H + h0;
-        if constexpr (BF16) {
-            const v4i raw = *(const v4i*)((const uint16_t*)hidden + row);
+    // eight positions at a time: their token ids and weights first, then every row load that is wanted (uniform over the
+    // workgroup), then the adds in sequence order -- taken one position at a time each row load waited for its id
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float w[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float lo = __uint_as_float((uint32_t)raw[i] << 16), hi = __uint_as_float((uint32_t)raw[i] & 0xFFFF0000u);
-                if (round_bf16 && w != 1.0f) {                   // instruction_mask * hidden is a bf16 product in the reference
-                    lo = __uint_as_float(f32_to_bf16_bits(lo * w) << 16);
-                    hi = __uint_as_float(f32_to_bf16_bits(hi * w) << 16);
-                    acc[2 * i] += lo;
-                    acc[2 * i + 1] += hi;
-                } else {
-                    acc[2 * i] += w * lo;
-                    acc[2 * i + 1] += w * hi;
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u;
+            const bool on = s < S && idr[s < S ? s : S - 1] != pad_id;
+            w[u] = on ? (ir ? ir[s] : 1.0f) : 0.0f;
+        }
+        if constexpr (BF16) {
+            v4i raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (w[u] != 0.0f) raw[u] = *(const v4i*)((const uint16_t*)hidden + ((size_t)b * S + s0 + u) * H + h0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (w[u] == 0.0f) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float lo = __uint_as_float((uint32_t)raw[u][i] << 16), hi = __uint_as_float((uint32_t)raw[u][i] & 0xFFFF0000u);
+                    if (round_bf16 && w[u] != 1.0f) {            // instruction_mask * hidden is a bf16 product in the reference
+                        lo = __uint_as_float(f32_to_bf16_bits(lo * w[u]) << 16);
+                        hi = __uint_as_float(f32_to_bf16_bits(hi * w[u]) << 16);
+                        acc[2 * i] += lo;
+                        acc[2 * i + 1] += hi;
+                    } else {
+                        acc[2 * i] += w[u] * lo;
+                        acc[2 * i + 1] += w[u] * hi;
+                    }
                 }
             }
         } else {
-            const v4f x0 = *(const v4f*)((const float*)hidden + row), x1 = *(const v4f*)((const float*)hidden + row + 4);
+            v4f x0[8], x1[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i] += w * x0[i];
-                acc[4 + i] += w * x1[i];
+            for (int u = 0; u < 8; ++u)
+                if (w[u] != 0.0f) {
+                    const float* src = (const float*)hidden + ((size_t)b * S + s0 + u) * H + h0;
+                    x0[u] = *(const v4f*)src;
+                    x1[u] = *(const v4f*)(src + 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (w[u] == 0.0f) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i] += w[u] * x0[u][i];
+                    acc[4 + i] += w[u] * x1[u][i];
+                }
             }
         }
     }
