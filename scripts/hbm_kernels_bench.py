@@ -41,3 +41,23 @@ hs = torch.randn((B, S, H), device=dev).to(torch.bfloat16)            # 3.8 GB
 ids = torch.randint(1, 1000, (B, S), device=dev)
 ms = timed(lambda: head.get_mean_token_embed(ids, hs, 0))
 print(f"mean_pool bf16 {B} x {S} x {H}: {ms:.3f} ms  {B * S * H * 2 / ms / 1e9:.2f} TB/s  (every position valid)")
+del hs, ids
+# the embedding head (exact-fp32 MFMA GEMMs, 157 TFLOP/s peak): forward = 2 GEMMs, backward = 4, each 2 B H Hd flop
+for Bh in (288, 8192):
+    H = Hd = 3584
+    mlp = head.MLP(H, Hd).to(dev)
+    with torch.no_grad():
+        mlp.linear_layer1.weight.add_(0.01 * torch.randn(Hd, H, device=dev))
+        mlp.linear_layer2.weight.add_(0.01 * torch.randn(H, Hd, device=dev))
+    xh = torch.randn((Bh, H), device=dev)
+    with torch.no_grad():
+        ms = timed(lambda: head._head(mlp, xh, normalize=True))
+    print(f"head forward   {Bh} x {H} x {Hd}: {ms:.3f} ms  {4.0 * Bh * H * Hd / ms / 1e9:.1f} TFLOP/s fp32")
+    xg = xh.clone().requires_grad_(True)
+    g = torch.randn((Bh, H), device=dev)
+
+    def fb():
+        out = head._head(mlp, xg, normalize=True)[0]
+        out.backward(g)
+    ms2 = timed(fb)
+    print(f"head fwd + bwd {Bh} x {H} x {Hd}: {ms2:.3f} ms  backward alone ~{ms2 - ms:.3f} ms = {8.0 * Bh * H * Hd / (ms2 - ms) / 1e9:.1f} TFLOP/s fp32")
