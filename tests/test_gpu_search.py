@@ -199,3 +199,28 @@ def test_any_embedding_width(compute, d):
         images = [(f"q{j}", q[j:j + 1]) for j in range(40)]
         cands = [(f"c{j}", c[j:j + 1]) for j in range(500)]
         assert search.get_topk_candidates(images, cands, 5, compute=compute) == oracle.get_topk_candidates(images, cands, 5)
+
+
+def test_per_sample_calls_keep_the_resident_corpus():
+    """The reference's loop passes the same corpus TENSOR to every negatives_for_sample call: its resident form is built once,
+    rebuilt when the tensor changes (in place, or another tensor), and gives the lists of the explicit Embeddings form."""
+    from vllm_amd import search
+    q, c = oracle.make_clustered(64, 900, 128, seed=21, n_centres=4)
+    q, c = oracle.bf16_round(q), oracle.bf16_round(c)
+    search.release_resident()
+    d1, d2 = {}, {}
+    search.negatives_for_sample(3, d1, q, c, top=20, compute="bf16")
+    first = search._resident_last[0][2]
+    search.negatives_for_sample(5, d1, q, c, top=20, compute="bf16")
+    assert search._resident_last[0][2] is first                       # kept
+    ce = search.Embeddings(c, "bf16")
+    search.negatives_for_sample(3, d2, q, ce, top=20, compute="bf16")
+    search.negatives_for_sample(5, d2, q, ce, top=20, compute="bf16")
+    assert d1 == d2
+    c[7] = c[3]                                                         # in place: the version counter moves
+    search.negatives_for_sample(3, d1, q, c, top=20, compute="bf16")
+    assert search._resident_last[0][2] is not first
+    search.negatives_for_sample(3, d2, q, search.Embeddings(c, "bf16"), top=20, compute="bf16")
+    assert d1[3] == d2[3]
+    search.release_resident()
+    assert not search._resident_last
